@@ -1,0 +1,1051 @@
+// ldc_kernels.hip -- gfx950 (MI355X) kernels + C ABI of libldc_hip.so.
+//
+// Hot path of the Chebyshev P_N-P_{N-2} artificial-compressibility lid-driven-cavity
+// solver (reference: src/solvers/spectral/sg.py, src/solvers/base.py:202-330), written
+// for CDNA4: fp64 MFMA (v_mfma_f64_16x16x4_f64), 64-wide waves, one 4-wave work-group
+// per 16x16 output tile with the contraction index split over the four SIMDs.
+//
+// Layout recap (include/ldc_hip.h): every array is LD x LD doubles, row-major, zero
+// padded, element [ix][iy]; each field has a transposed copy.  With that, EVERY product
+// on the path is of the "NT" form   C[i][j] = sum_k X[i][k] * Y[j][k]   and an MFMA
+// operand is one contiguous 32-byte run per lane (a full 128-byte line per 4 lanes):
+//
+//   d/dx  (Dx @ U)[i][j]   = sum_k Dx[i][k] * UT[j][k]
+//   d/dy  (U @ Dy^T)[i][j] = sum_k U [i][k] * Dy[j][k]
+//
+// MFMA lane maps (v_mfma_f64_16x16x4_f64; pinned by tests/test_gpu_mfma.py):
+//   A: lane l holds A[row l&15][k l>>4]      B: lane l holds B[k l>>4][col l&15]
+//   D: lane l, reg r holds D[row (l>>4)+4r][col l&15]
+// A lane loads 4 consecutive k (k0+4q .. k0+4q+3, q = l>>4) and feeds element s to the
+// s-th of four MFMAs, i.e. k-step s contracts k = k0 + 4q + s: any bijection of k works
+// as long as A and B use the same one.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+#include "ldc_hip.h"
+
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+#define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+constexpr int kWaves = 4;          // waves per work-group == K-split factor
+constexpr int kThreads = 256;
+
+// ---------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ v4d ldfrag(const double* X, int ld, int r0, int k0, int lane) {
+  return *reinterpret_cast<const v4d*>(X + (size_t)(r0 + (lane & 15)) * ld + k0 + 4 * (lane >> 4));
+}
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+__device__ __forceinline__ double wave_max(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o));
+  return x;
+}
+// wave-cooperative dot product of two contiguous rows (fixed order => deterministic)
+__device__ __forceinline__ double dot_rows(const double* a, const double* b, int n, int lane) {
+  double s = 0.0;
+  for (int k = lane; k < n; k += 64) s += a[k] * b[k];
+  return wave_sum(s);
+}
+
+// Sum the four waves' partial accumulators through LDS.  After the call thread
+// (wv, lane) owns tile element  row = (lane>>4) + 4*wv,  col = lane&15.
+template <int NA>
+__device__ __forceinline__ void kreduce(const v4d (&acc)[NA], double* red, int lane, int wv,
+                                        double (&out)[NA]) {
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((wv * NA + a) * 4 + r) * 64 + lane] = acc[a][r];
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    double s = red[((0 * NA + a) * 4 + wv) * 64 + lane];
+    s += red[((1 * NA + a) * 4 + wv) * 64 + lane];
+    s += red[((2 * NA + a) * 4 + wv) * 64 + lane];
+    s += red[((3 * NA + a) * 4 + wv) * 64 + lane];
+    out[a] = s;
+  }
+}
+
+// block-wide reduction of NV sums and NM maxima into partials[]; all threads call.
+template <int NV, int NM>
+__device__ __forceinline__ void block_reduce_store(double (&sums)[NV], double (&maxs)[NM > 0 ? NM : 1],
+                                                   double* sm, double* dst, int lane, int wv) {
+#pragma unroll
+  for (int v = 0; v < NV; ++v) sums[v] = wave_sum(sums[v]);
+#pragma unroll
+  for (int v = 0; v < NM; ++v) maxs[v] = wave_max(maxs[v]);
+  __syncthreads();   // sm may alias the kreduce buffer
+  if (lane == 0) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) sm[wv * (NV + NM) + v] = sums[v];
+#pragma unroll
+    for (int v = 0; v < NM; ++v) sm[wv * (NV + NM) + NV + v] = maxs[v];
+  }
+  __syncthreads();
+  const int t = wv * 64 + lane;
+  if (t < NV) {
+    dst[t] = ((sm[t] + sm[(NV + NM) + t]) + sm[2 * (NV + NM) + t]) + sm[3 * (NV + NM) + t];
+  } else if (t < NV + NM) {
+    dst[t] = fmax(fmax(sm[t], sm[(NV + NM) + t]), fmax(sm[2 * (NV + NM) + t], sm[3 * (NV + NM) + t]));
+  }
+}
+
+// blockIdx -> tile.  Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an
+// L2), so give each XCD a compact (T/2 x T/4 when T%8==0) patch of tiles: the operand
+// panels it re-reads then stay in its own L2.  Pure speed; any bijection is correct.
+__device__ __forceinline__ void tile_of_block(int b, int T, int& I, int& J) {
+  if ((T & 7) == 0) {
+    const int xcd = b & 7, loc = b >> 3;          // loc in [0, T*T/8)
+    const int pr = T / 4, pc = T / 2;             // patch rows/cols: 4 x 2 patches
+    const int pI = xcd >> 1, pJ = xcd & 1;
+    I = pI * pr + loc / pc;
+    J = pJ * pc + loc % pc;
+  } else {
+    I = b / T;
+    J = b % T;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// RK stage kernel
+// ---------------------------------------------------------------------------------------
+struct StageArgs {
+  int M, LD, T, tail;
+  double nu, beta2, alpha;
+  const double *Dx, *D2x, *Dy, *D2y, *IxF, *GxF;
+  const double *Uin, *UinT, *Vin, *VinT;  // stage input state
+  const double *U0, *V0, *P0;             // step-start state (aliases the outputs when LAST)
+  const double *T1T, *T2T;                // pressure transforms (GP only)
+  double *PX, *PY;                        // grad p: written when GP, read otherwise
+  double *Uout, *UoutT, *Vout, *VoutT, *Pout;
+  const double *ulid, *wx, *wy;
+  const double* scal;
+  const int* ctrl;
+  double* partials;
+  double* dump[11];
+};
+
+struct NodeDerivs {
+  double ux, vx, uy, vy, lu, lv, px, py;
+};
+
+// Everything the residual needs at ONE node, by full-length dot products (edge nodes of
+// the `tail` case: index M-1 is outside the MFMA tiles).  Wave-cooperative.
+__device__ __forceinline__ NodeDerivs edge_node(const StageArgs& a, int i, int j, int lane, bool gp) {
+  const int n = a.M, ld = a.LD;
+  const double *dxi = a.Dx + (size_t)i * ld, *d2xi = a.D2x + (size_t)i * ld;
+  const double *dyj = a.Dy + (size_t)j * ld, *d2yj = a.D2y + (size_t)j * ld;
+  const double *ui = a.Uin + (size_t)i * ld, *vi = a.Vin + (size_t)i * ld;
+  const double *utj = a.UinT + (size_t)j * ld, *vtj = a.VinT + (size_t)j * ld;
+  NodeDerivs d;
+  d.ux = dot_rows(dxi, utj, n, lane);
+  d.vx = dot_rows(dxi, vtj, n, lane);
+  d.uy = dot_rows(ui, dyj, n, lane);
+  d.vy = dot_rows(vi, dyj, n, lane);
+  d.lu = dot_rows(d2xi, utj, n, lane) + dot_rows(ui, d2yj, n, lane);
+  d.lv = dot_rows(d2xi, vtj, n, lane) + dot_rows(vi, d2yj, n, lane);
+  if (gp) {
+    d.px = dot_rows(a.GxF + (size_t)i * ld, a.T1T + (size_t)j * ld, n, lane);
+    d.py = dot_rows(a.IxF + (size_t)i * ld, a.T2T + (size_t)j * ld, n, lane);
+  } else {
+    d.px = a.PX[(size_t)i * ld + j];
+    d.py = a.PY[(size_t)i * ld + j];
+  }
+  return d;
+}
+
+// slots of the stage-4 partial sums
+enum { PS_DU2 = 0, PS_DV2, PS_U02, PS_V02, PS_RU2, PS_RV2, PS_RP2, PS_E, PS_NSUM, PS_UMAX = PS_NSUM, PS_VMAX, PS_N };
+static_assert(PS_N <= LDC_NPART, "partials row too small");
+
+// GP   : also contract the pressure transforms (px, py) and store them
+// LAST : stage 4 -- pressure update, in-place state, reductions, edge-node residuals
+// DUMP : parity-test mode, writes every intermediate, touches no state
+template <bool GP, bool LAST, bool DUMP>
+__global__ __launch_bounds__(kThreads) void stage_kernel(const StageArgs a) {
+  constexpr int NA = GP ? 8 : 6;
+  __shared__ __attribute__((aligned(16))) double red[kWaves * NA * 4 * 64];
+
+  if (!DUMP && a.ctrl[LDC_CTRL_DONE] != 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int M = a.M, LD = a.LD, T = a.T;
+  const int nt = T * T;
+  const double dt = a.scal[LDC_SCAL_DT];
+  const double adt = a.alpha * dt;
+
+  if ((int)blockIdx.x >= nt) {
+    // ---- edge nodes (tail case; only launched for LAST or DUMP) -----------------------
+    const int e = ((int)blockIdx.x - nt) * kWaves + wv;   // one wave per node
+    const int m1 = M - 1;
+    double sums[PS_NSUM] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double maxs[2] = {0, 0};
+    if (e < 2 * M - 1) {
+      const int i = (e < M) ? m1 : (e - M);
+      const int j = (e < M) ? e : m1;
+      const NodeDerivs d = edge_node(a, i, j, lane, GP || DUMP);
+      const size_t ij = (size_t)i * LD + j;
+      const double u = a.Uin[ij], v = a.Vin[ij];
+      const double Ru = -(u * d.ux + v * d.uy) - d.px + a.nu * d.lu;
+      const double Rv = -(u * d.vx + v * d.vy) - d.py + a.nu * d.lv;
+      if (DUMP) {
+        if (lane == 0) {
+          a.dump[0][ij] = d.ux; a.dump[1][ij] = d.uy; a.dump[2][ij] = d.vx; a.dump[3][ij] = d.vy;
+          a.dump[4][ij] = d.lu; a.dump[5][ij] = d.lv; a.dump[6][ij] = d.px; a.dump[7][ij] = d.py;
+          a.dump[8][ij] = Ru;   a.dump[9][ij] = Rv;
+        }
+      } else if (lane == 0) {
+        const double u0 = a.U0[ij], v0 = a.V0[ij];   // boundary values never change
+        sums[PS_U02] = u0 * u0; sums[PS_V02] = v0 * v0;
+        sums[PS_RU2] = Ru * Ru; sums[PS_RV2] = Rv * Rv;
+        sums[PS_E] = a.wx[i] * a.wy[j] * (u0 * u0 + v0 * v0);
+        maxs[0] = fabs(u0); maxs[1] = fabs(v0);
+      }
+    }
+    if (!DUMP) block_reduce_store<PS_NSUM, 2>(sums, maxs, red, a.partials + (size_t)blockIdx.x * LDC_NPART, lane, wv);
+    return;
+  }
+
+  int I, J;
+  tile_of_block((int)blockIdx.x, T, I, J);
+  const int r0 = 16 * I, c0 = 16 * J;
+
+  // ---- contraction over k, split over the four waves ----------------------------------
+  v4d acc[NA];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+  // acc: 0 ux, 1 vx, 2 uy, 3 vy, 4 lap u, 5 lap v, (6 px, 7 py)
+  for (int g = wv; g < T; g += kWaves) {
+    const int k0 = 16 * g;
+    const v4d fDx = ldfrag(a.Dx, LD, r0, k0, lane), fD2x = ldfrag(a.D2x, LD, r0, k0, lane);
+    const v4d fUT = ldfrag(a.UinT, LD, c0, k0, lane), fVT = ldfrag(a.VinT, LD, c0, k0, lane);
+    const v4d fU = ldfrag(a.Uin, LD, r0, k0, lane), fV = ldfrag(a.Vin, LD, r0, k0, lane);
+    const v4d fDy = ldfrag(a.Dy, LD, c0, k0, lane), fD2y = ldfrag(a.D2y, LD, c0, k0, lane);
+    v4d fGx, fIx, fT1, fT2;
+    if (GP) {
+      fGx = ldfrag(a.GxF, LD, r0, k0, lane); fIx = ldfrag(a.IxF, LD, r0, k0, lane);
+      fT1 = ldfrag(a.T1T, LD, c0, k0, lane); fT2 = ldfrag(a.T2T, LD, c0, k0, lane);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      acc[0] = MFMA_F64(fDx[s], fUT[s], acc[0]);
+      acc[1] = MFMA_F64(fDx[s], fVT[s], acc[1]);
+      acc[2] = MFMA_F64(fU[s], fDy[s], acc[2]);
+      acc[3] = MFMA_F64(fV[s], fDy[s], acc[3]);
+      acc[4] = MFMA_F64(fD2x[s], fUT[s], acc[4]);
+      acc[5] = MFMA_F64(fD2x[s], fVT[s], acc[5]);
+      if (GP) {
+        acc[6] = MFMA_F64(fGx[s], fT1[s], acc[6]);
+        acc[7] = MFMA_F64(fIx[s], fT2[s], acc[7]);
+      }
+      acc[4] = MFMA_F64(fU[s], fD2y[s], acc[4]);
+      acc[5] = MFMA_F64(fV[s], fD2y[s], acc[5]);
+    }
+  }
+  double s[NA];
+  kreduce<NA>(acc, red, lane, wv, s);
+
+  // ---- pointwise epilogue: thread owns node (i, j) -------------------------------------
+  const int ti = 4 * wv + (lane >> 4), tj = lane & 15;
+  const int i = r0 + ti, j = c0 + tj;
+  const size_t ij = (size_t)i * LD + j;
+  const bool valid = (i < M) && (j < M);
+  const bool interior = (i >= 1) && (i <= M - 2) && (j >= 1) && (j <= M - 2);
+  const double uin = a.Uin[ij], vin = a.Vin[ij];
+  double ux = s[0], vx = s[1], uy = s[2], vy = s[3], lu = s[4], lv = s[5];
+  if (a.tail) {
+    // k = M-1 lies outside the MFMA range: exact rank-1 completion of every contraction
+    const int m1 = M - 1;
+    const double dxl = a.Dx[(size_t)i * LD + m1], d2xl = a.D2x[(size_t)i * LD + m1];
+    const double dyl = a.Dy[(size_t)j * LD + m1], d2yl = a.D2y[(size_t)j * LD + m1];
+    const double ue = a.Uin[(size_t)m1 * LD + j], ve = a.Vin[(size_t)m1 * LD + j];
+    const double un = a.Uin[(size_t)i * LD + m1], vn = a.Vin[(size_t)i * LD + m1];
+    ux += dxl * ue; vx += dxl * ve;
+    uy += un * dyl; vy += vn * dyl;
+    lu += d2xl * ue + un * d2yl;
+    lv += d2xl * ve + vn * d2yl;
+  }
+  double px, py;
+  if (GP) {
+    px = valid ? s[NA - 2] : 0.0;   // T1T/T2T rows of index M-1 are zero: no completion term
+    py = valid ? s[NA - 1] : 0.0;
+    if (!DUMP) { a.PX[ij] = px; a.PY[ij] = py; }
+  } else {
+    px = a.PX[ij]; py = a.PY[ij];
+  }
+  const double Ru = -(uin * ux + vin * uy) - px + a.nu * lu;
+  const double Rv = -(uin * vx + vin * vy) - py + a.nu * lv;
+  const double Rp = -a.beta2 * (ux + vy);
+
+  if (DUMP) {
+    if (valid) {
+      a.dump[0][ij] = ux; a.dump[1][ij] = uy; a.dump[2][ij] = vx; a.dump[3][ij] = vy;
+      a.dump[4][ij] = lu; a.dump[5][ij] = lv; a.dump[6][ij] = px; a.dump[7][ij] = py;
+      a.dump[8][ij] = Ru; a.dump[9][ij] = Rv;
+      if (interior) a.dump[10][ij] = Rp;
+    }
+    return;
+  }
+
+  const double u0 = a.U0[ij], v0 = a.V0[ij];
+  double un = u0 + adt * Ru, vn = v0 + adt * Rv;
+  // walls first, lid last (sg.py:348-385): the lid row wins the two top corners
+  if (!valid) { un = 0.0; vn = 0.0; }
+  else if (j == M - 1) { un = a.ulid[i]; vn = 0.0; }
+  else if (i == 0 || i == M - 1 || j == 0) { un = 0.0; vn = 0.0; }
+  a.Uout[ij] = un;
+  a.Vout[ij] = vn;
+  if (a.Pout != nullptr) a.Pout[ij] = interior ? (a.P0[ij] + adt * Rp) : 0.0;
+
+  // transposed copies through LDS (the reduction buffer is free again after a barrier)
+  __syncthreads();
+  double* tu = red;
+  double* tv = red + 16 * 17;
+  tu[ti * 17 + tj] = un;
+  tv[ti * 17 + tj] = vn;
+  __syncthreads();
+  {
+    const int tr = tid >> 4, tc = tid & 15;   // write UT[c0+tr][r0+tc] = tile[tc][tr]
+    const size_t o = (size_t)(c0 + tr) * LD + r0 + tc;
+    a.UoutT[o] = tu[tc * 17 + tr];
+    a.VoutT[o] = tv[tc * 17 + tr];
+  }
+
+  if (LAST) {
+    double sums[PS_NSUM];
+    double maxs[2];
+    const double du = un - u0, dv = vn - v0;
+    sums[PS_DU2] = valid ? du * du : 0.0;
+    sums[PS_DV2] = valid ? dv * dv : 0.0;
+    sums[PS_U02] = valid ? u0 * u0 : 0.0;
+    sums[PS_V02] = valid ? v0 * v0 : 0.0;
+    sums[PS_RU2] = valid ? Ru * Ru : 0.0;
+    sums[PS_RV2] = valid ? Rv * Rv : 0.0;
+    sums[PS_RP2] = interior ? Rp * Rp : 0.0;
+    sums[PS_E] = valid ? a.wx[i] * a.wy[j] * (un * un + vn * vn) : 0.0;
+    maxs[0] = fabs(un);
+    maxs[1] = fabs(vn);
+    block_reduce_store<PS_NSUM, 2>(sums, maxs, red + 2 * 16 * 17, a.partials + (size_t)blockIdx.x * LDC_NPART, lane, wv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// "post" kernel: pressure transform T1T/T2T (+ vorticity and enstrophy partials)
+// ---------------------------------------------------------------------------------------
+struct PostArgs {
+  int M, LD, T, tail, do_omega;
+  const double *Dx, *Dy, *IyF, *GyF;
+  const double *U, *V, *VT, *P;
+  double *T1T, *T2T, *W, *WT;
+  const double *wx, *wy;
+  const int* ctrl;
+  double* partZ;   // one double per block (stride LDC_NPART)
+  int ignore_latch;
+};
+
+__global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a) {
+  __shared__ __attribute__((aligned(16))) double red[kWaves * 2 * 4 * 64];
+  if (!a.ignore_latch && a.ctrl[LDC_CTRL_DONE] != 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int M = a.M, LD = a.LD, T = a.T, nt = T * T, m1 = M - 1;
+  int b = (int)blockIdx.x;
+
+  if (b < nt) {
+    // ---- T1T[j][i] = sum_k P[i][k] IyF[j][k],  T2T[j][i] = sum_k P[i][k] GyF[j][k] -------
+    int I, J;
+    tile_of_block(b, T, I, J);
+    const int r0 = 16 * I, c0 = 16 * J;
+    v4d acc[2] = {(v4d){0, 0, 0, 0}, (v4d){0, 0, 0, 0}};
+    for (int g = wv; g < T; g += kWaves) {
+      const int k0 = 16 * g;
+      const v4d fP = ldfrag(a.P, LD, r0, k0, lane);
+      const v4d fI = ldfrag(a.IyF, LD, c0, k0, lane), fG = ldfrag(a.GyF, LD, c0, k0, lane);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[0] = MFMA_F64(fP[s], fI[s], acc[0]);
+        acc[1] = MFMA_F64(fP[s], fG[s], acc[1]);
+      }
+    }
+    double s[2];
+    kreduce<2>(acc, red, lane, wv, s);
+    const int ti = 4 * wv + (lane >> 4), tj = lane & 15;
+    __syncthreads();
+    double* t1 = red;
+    double* t2 = red + 16 * 17;
+    t1[ti * 17 + tj] = s[0];
+    t2[ti * 17 + tj] = s[1];
+    __syncthreads();
+    const int tr = tid >> 4, tc = tid & 15;
+    const size_t o = (size_t)(c0 + tr) * LD + r0 + tc;
+    const bool ok = (c0 + tr < M) && (r0 + tc < M);
+    a.T1T[o] = ok ? t1[tc * 17 + tr] : 0.0;
+    a.T2T[o] = ok ? t2[tc * 17 + tr] : 0.0;
+    return;
+  }
+  b -= nt;
+  const int nPedge = a.tail ? (M + kWaves - 1) / kWaves : 0;
+  if (b < nPedge) {
+    // ---- tail: row M-1 of T1T/T2T = P @ IyF[M-1,:], one wave per k -----------------------
+    const int k = b * kWaves + wv;
+    if (k < M) {
+      const double* pk = a.P + (size_t)k * LD;
+      const double t1 = dot_rows(pk, a.IyF + (size_t)m1 * LD, M, lane);
+      const double t2 = dot_rows(pk, a.GyF + (size_t)m1 * LD, M, lane);
+      if (lane == 0) { a.T1T[(size_t)m1 * LD + k] = t1; a.T2T[(size_t)m1 * LD + k] = t2; }
+    }
+    return;
+  }
+  b -= nPedge;
+  if (!a.do_omega) return;
+  if (b < nt) {
+    // ---- omega = Dx @ V - U @ Dy^T, enstrophy partial ---------------------------------------
+    int I, J;
+    tile_of_block(b, T, I, J);
+    const int r0 = 16 * I, c0 = 16 * J;
+    v4d acc[2] = {(v4d){0, 0, 0, 0}, (v4d){0, 0, 0, 0}};
+    for (int g = wv; g < T; g += kWaves) {
+      const int k0 = 16 * g;
+      const v4d fDx = ldfrag(a.Dx, LD, r0, k0, lane), fVT = ldfrag(a.VT, LD, c0, k0, lane);
+      const v4d fU = ldfrag(a.U, LD, r0, k0, lane), fDy = ldfrag(a.Dy, LD, c0, k0, lane);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[0] = MFMA_F64(fDx[s], fVT[s], acc[0]);
+        acc[1] = MFMA_F64(fU[s], fDy[s], acc[1]);
+      }
+    }
+    double s[2];
+    kreduce<2>(acc, red, lane, wv, s);
+    const int ti = 4 * wv + (lane >> 4), tj = lane & 15;
+    const int i = r0 + ti, j = c0 + tj;
+    const bool valid = (i < M) && (j < M);
+    double vx = s[0], uy = s[1];
+    if (a.tail) {
+      vx += a.Dx[(size_t)i * LD + m1] * a.V[(size_t)m1 * LD + j];
+      uy += a.U[(size_t)i * LD + m1] * a.Dy[(size_t)j * LD + m1];
+    }
+    const double w = valid ? (vx - uy) : 0.0;
+    a.W[(size_t)i * LD + j] = w;
+    __syncthreads();
+    double* tw = red;
+    tw[ti * 17 + tj] = w;
+    __syncthreads();
+    const int tr = tid >> 4, tc = tid & 15;
+    a.WT[(size_t)(c0 + tr) * LD + r0 + tc] = tw[tc * 17 + tr];
+    double sums[1] = {valid ? a.wx[i] * a.wy[j] * w * w : 0.0};
+    double dummy[1] = {0.0};
+    block_reduce_store<1, 0>(sums, dummy, red + 16 * 17, a.partZ + (size_t)b * LDC_NPART, lane, wv);
+    return;
+  }
+  b -= nt;
+  {
+    // ---- tail: omega on the row/column of index M-1 ------------------------------------------
+    const int e = b * kWaves + wv;
+    double sums[1] = {0.0};
+    double dummy[1] = {0.0};
+    if (e < 2 * M - 1) {
+      const int i = (e < M) ? m1 : (e - M);
+      const int j = (e < M) ? e : m1;
+      const double vx = dot_rows(a.Dx + (size_t)i * LD, a.VT + (size_t)j * LD, M, lane);
+      const double uy = dot_rows(a.U + (size_t)i * LD, a.Dy + (size_t)j * LD, M, lane);
+      const double w = vx - uy;
+      if (lane == 0) {
+        a.W[(size_t)i * LD + j] = w;
+        a.WT[(size_t)j * LD + i] = w;
+        sums[0] = a.wx[i] * a.wy[j] * w * w;
+      }
+    }
+    block_reduce_store<1, 0>(sums, dummy, red, a.partZ + (size_t)(nt + b) * LDC_NPART, lane, wv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// palinstrophy kernel:  P = 1/2 sum W ((Dx w)^2 + (w Dy^T)^2)
+// ---------------------------------------------------------------------------------------
+struct PalinArgs {
+  int M, LD, T, tail;
+  const double *Dx, *Dy, *W, *WT, *wx, *wy;
+  const int* ctrl;
+  double* partP;
+  int ignore_latch;
+};
+
+__global__ __launch_bounds__(kThreads) void palin_kernel(const PalinArgs a) {
+  __shared__ __attribute__((aligned(16))) double red[kWaves * 2 * 4 * 64];
+  if (!a.ignore_latch && a.ctrl[LDC_CTRL_DONE] != 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int M = a.M, LD = a.LD, T = a.T, nt = T * T, m1 = M - 1;
+  const int b = (int)blockIdx.x;
+  double sums[1] = {0.0};
+  double dummy[1] = {0.0};
+  if (b < nt) {
+    int I, J;
+    tile_of_block(b, T, I, J);
+    const int r0 = 16 * I, c0 = 16 * J;
+    v4d acc[2] = {(v4d){0, 0, 0, 0}, (v4d){0, 0, 0, 0}};
+    for (int g = wv; g < T; g += kWaves) {
+      const int k0 = 16 * g;
+      const v4d fDx = ldfrag(a.Dx, LD, r0, k0, lane), fWT = ldfrag(a.WT, LD, c0, k0, lane);
+      const v4d fW = ldfrag(a.W, LD, r0, k0, lane), fDy = ldfrag(a.Dy, LD, c0, k0, lane);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[0] = MFMA_F64(fDx[s], fWT[s], acc[0]);
+        acc[1] = MFMA_F64(fW[s], fDy[s], acc[1]);
+      }
+    }
+    double s[2];
+    kreduce<2>(acc, red, lane, wv, s);
+    const int i = r0 + 4 * wv + (lane >> 4), j = c0 + (lane & 15);
+    const bool valid = (i < M) && (j < M);
+    double gx = s[0], gy = s[1];
+    if (a.tail) {
+      gx += a.Dx[(size_t)i * LD + m1] * a.W[(size_t)m1 * LD + j];
+      gy += a.W[(size_t)i * LD + m1] * a.Dy[(size_t)j * LD + m1];
+    }
+    sums[0] = valid ? a.wx[i] * a.wy[j] * (gx * gx + gy * gy) : 0.0;
+  } else {
+    const int e = (b - nt) * kWaves + wv;
+    if (e < 2 * M - 1) {
+      const int i = (e < M) ? m1 : (e - M);
+      const int j = (e < M) ? e : m1;
+      const double gx = dot_rows(a.Dx + (size_t)i * LD, a.WT + (size_t)j * LD, M, lane);
+      const double gy = dot_rows(a.W + (size_t)i * LD, a.Dy + (size_t)j * LD, M, lane);
+      if (lane == 0) sums[0] = a.wx[i] * a.wy[j] * (gx * gx + gy * gy);
+    }
+  }
+  block_reduce_store<1, 0>(sums, dummy, red, a.partP + (size_t)b * LDC_NPART, lane, wv);
+}
+
+// ---------------------------------------------------------------------------------------
+// finalize: one work-group folds the per-block partials in a fixed order
+// ---------------------------------------------------------------------------------------
+struct FinalArgs {
+  int nblk4, nblkZ, nblkP;   // rows in each slab
+  int with_diag, warmup, nan_guard, rec_cap;
+  double cfl, beta2, nu, hx, hy, lid, tol;
+  const double *part4, *partZ, *partP;
+  double* scal;
+  int* ctrl;
+  double* rec;
+};
+
+__device__ __forceinline__ double next_dt(double umax, double vmax, const FinalArgs& a) {
+  const double um = fmax(umax, a.lid), vm = fmax(vmax, 1e-10);
+  const double lx = (um + sqrt(um * um + a.beta2)) / a.hx + a.nu / (a.hx * a.hx);
+  const double ly = (vm + sqrt(vm * vm + a.beta2)) / a.hy + a.nu / (a.hy * a.hy);
+  return a.cfl / (lx + ly);
+}
+
+__global__ __launch_bounds__(kThreads) void finalize_kernel(const FinalArgs a) {
+  __shared__ double sm[kThreads * (PS_N + 2)];
+  if (a.ctrl[LDC_CTRL_DONE] != 0) return;
+  const int t = threadIdx.x;
+  double v[PS_N + 2];
+#pragma unroll
+  for (int q = 0; q < PS_N + 2; ++q) v[q] = 0.0;
+  for (int r = t; r < a.nblk4; r += kThreads) {
+    const double* p = a.part4 + (size_t)r * LDC_NPART;
+#pragma unroll
+    for (int q = 0; q < PS_NSUM; ++q) v[q] += p[q];
+    v[PS_UMAX] = fmax(v[PS_UMAX], p[PS_UMAX]);
+    v[PS_VMAX] = fmax(v[PS_VMAX], p[PS_VMAX]);
+  }
+  if (a.with_diag) {
+    for (int r = t; r < a.nblkZ; r += kThreads) v[PS_N] += a.partZ[(size_t)r * LDC_NPART];
+    for (int r = t; r < a.nblkP; r += kThreads) v[PS_N + 1] += a.partP[(size_t)r * LDC_NPART];
+  }
+#pragma unroll
+  for (int q = 0; q < PS_N + 2; ++q) sm[q * kThreads + t] = v[q];
+  __syncthreads();
+  for (int h = kThreads / 2; h > 0; h >>= 1) {
+    if (t < h) {
+#pragma unroll
+      for (int q = 0; q < PS_N + 2; ++q) {
+        const bool is_max = (q == PS_UMAX || q == PS_VMAX);
+        const double x = sm[q * kThreads + t], y = sm[q * kThreads + t + h];
+        sm[q * kThreads + t] = is_max ? fmax(x, y) : (x + y);
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    double r[PS_N + 2];
+#pragma unroll
+    for (int q = 0; q < PS_N + 2; ++q) r[q] = sm[q * kThreads];
+    const double relu = sqrt(r[PS_DU2]) / (sqrt(r[PS_U02]) + 1e-12);
+    const double relv = sqrt(r[PS_DV2]) / (sqrt(r[PS_V02]) + 1e-12);
+    // Python's max(a, b) returns a unless b > a: a NaN in relv is dropped, one in relu sticks
+    const double rel = (relv > relu) ? relv : relu;
+    const int it = a.ctrl[LDC_CTRL_ITER];           // 0-based index of this iteration
+    double* rec = a.rec + (size_t)(it % a.rec_cap) * LDC_REC_LEN;
+    rec[LDC_REC_REL] = rel;
+    rec[LDC_REC_RU] = sqrt(r[PS_RU2]);
+    rec[LDC_REC_RV] = sqrt(r[PS_RV2]);
+    rec[LDC_REC_RP] = sqrt(r[PS_RP2]);
+    rec[LDC_REC_E] = 0.5 * r[PS_E];
+    rec[LDC_REC_Z] = 0.5 * r[PS_N];
+    rec[LDC_REC_P] = 0.5 * r[PS_N + 1];
+    rec[LDC_REC_DT] = a.scal[LDC_SCAL_DT];
+    a.scal[LDC_SCAL_UMAX] = r[PS_UMAX];
+    a.scal[LDC_SCAL_VMAX] = r[PS_VMAX];
+    a.scal[LDC_SCAL_DT] = next_dt(r[PS_UMAX], r[PS_VMAX], a);
+    a.ctrl[LDC_CTRL_ITER] = it + 1;
+    if (it >= a.warmup && rel < a.tol) a.ctrl[LDC_CTRL_DONE] = 1;
+    else if (a.nan_guard && !(fabs(rel) <= 1.79769313486231570815e308)) a.ctrl[LDC_CTRL_DONE] = 2;
+  }
+}
+
+// dt of the very first iteration: max |u|, max |v| over the whole padded arrays
+__global__ __launch_bounds__(kThreads) void prime_kernel(const double* U, const double* V, int n, FinalArgs a) {
+  __shared__ double sm[2 * kWaves];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  double mu = 0.0, mv = 0.0;
+  for (int q = t; q < n; q += kThreads) { mu = fmax(mu, fabs(U[q])); mv = fmax(mv, fabs(V[q])); }
+  mu = wave_max(mu); mv = wave_max(mv);
+  if (lane == 0) { sm[wv] = mu; sm[kWaves + wv] = mv; }
+  __syncthreads();
+  if (t == 0) {
+    mu = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+    mv = fmax(fmax(sm[4], sm[5]), fmax(sm[6], sm[7]));
+    a.scal[LDC_SCAL_UMAX] = mu;
+    a.scal[LDC_SCAL_VMAX] = mv;
+    a.scal[LDC_SCAL_DT] = next_dt(mu, mv, a);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// generic NT product (stream-function solve)
+// ---------------------------------------------------------------------------------------
+struct GemmArgs {
+  const double *A, *B;
+  double* C;
+  int R, K, LD, transpose_out, scale_mode;
+  const double *lam_r, *lam_c;
+};
+
+__global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) double red[kWaves * 1 * 4 * 64 + 16 * 17];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int I = blockIdx.y, J = blockIdx.x, r0 = 16 * I, c0 = 16 * J;
+  v4d acc[1] = {(v4d){0, 0, 0, 0}};
+  for (int g = wv; g < a.K; g += kWaves) {
+    const v4d fA = ldfrag(a.A, a.LD, r0, 16 * g, lane), fB = ldfrag(a.B, a.LD, c0, 16 * g, lane);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[0] = MFMA_F64(fA[s], fB[s], acc[0]);
+  }
+  double s[1];
+  kreduce<1>(acc, red, lane, wv, s);
+  const int ti = 4 * wv + (lane >> 4), tj = lane & 15;
+  double c = s[0];
+  if (a.scale_mode == 1) c /= (a.lam_r[r0 + ti] + a.lam_c[c0 + tj]);
+  if (!a.transpose_out) {
+    a.C[(size_t)(r0 + ti) * a.LD + c0 + tj] = c;
+  } else {
+    double* tt = red + kWaves * 4 * 64;
+    tt[ti * 17 + tj] = c;
+    __syncthreads();
+    const int tr = tid >> 4, tc = tid & 15;
+    a.C[(size_t)(c0 + tr) * a.LD + r0 + tc] = tt[tc * 17 + tr];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// vortex extrema (sg.py:621-709): first index in C order wins ties, like numpy.argmin/argmax
+// ---------------------------------------------------------------------------------------
+struct Best { double v; int idx; };
+__device__ __forceinline__ void take_min(Best& b, double v, int idx) {
+  if (v < b.v || (v == b.v && idx < b.idx)) { b.v = v; b.idx = idx; }
+}
+__device__ __forceinline__ void take_max(Best& b, double v, int idx) {
+  if (v > b.v || (v == b.v && idx < b.idx)) { b.v = v; b.idx = idx; }
+}
+
+__global__ __launch_bounds__(1024) void extrema_kernel(const double* Psi, const double* W, const double* x,
+                                                      const double* y, int M, int LD, double* out_val,
+                                                      int32_t* out_idx) {
+  __shared__ double sv[5][1024];
+  __shared__ int si[5][1024];
+  const int t = threadIdx.x;
+  const double inf = __builtin_huge_val();
+  Best b[5] = {{inf, 0x7fffffff}, {-inf, 0x7fffffff}, {-inf, 0x7fffffff}, {-inf, 0x7fffffff}, {-inf, 0x7fffffff}};
+  for (int q = t; q < M * M; q += 1024) {
+    const int i = q / M, j = q % M;
+    const int idx = i * LD + j;
+    const double p = Psi[idx], w = W[idx], xi = x[i], yj = y[j];
+    take_min(b[0], p, q);
+    take_max(b[1], fabs(w), q);
+    take_max(b[2], (xi > 0.5 && yj < 0.5) ? p : -inf, q);
+    take_max(b[3], (xi < 0.5 && yj < 0.5) ? p : -inf, q);
+    take_max(b[4], (xi < 0.5 && yj > 0.5) ? p : -inf, q);
+  }
+  for (int k = 0; k < 5; ++k) { sv[k][t] = b[k].v; si[k][t] = b[k].idx; }
+  __syncthreads();
+  for (int h = 512; h > 0; h >>= 1) {
+    if (t < h) {
+      for (int k = 0; k < 5; ++k) {
+        Best m = {sv[k][t], si[k][t]};
+        if (k == 0) take_min(m, sv[k][t + h], si[k][t + h]); else take_max(m, sv[k][t + h], si[k][t + h]);
+        sv[k][t] = m.v; si[k][t] = m.idx;
+      }
+    }
+    __syncthreads();
+  }
+  if (t < 5) {
+    const int q = si[t][0];
+    const int i = q / M, j = q % M;
+    out_idx[t] = i * LD + j;
+    out_val[t] = (t == 1) ? W[i * LD + j] : sv[t][0];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// hardware self-tests
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void mfma_selftest_kernel(const double* A, const double* B, double* D) {
+  const int l = threadIdx.x;
+  const double a = A[(l & 15) * 4 + (l >> 4)];   // A is 16 x 4 row-major
+  const double b = B[(l >> 4) * 16 + (l & 15)];  // B is 4 x 16 row-major
+  v4d c = {0, 0, 0, 0};
+  c = MFMA_F64(a, b, c);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) D[((l >> 4) + 4 * r) * 16 + (l & 15)] = c[r];
+}
+
+__global__ __launch_bounds__(kThreads) void mfma_peak_kernel(double* sink, int iters) {
+  const int l = threadIdx.x;
+  double a = 1.0 + 1e-9 * l, b = 1.0 - 1e-9 * l;
+  v4d c[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) c[q] = (v4d){0.0, 0.0, 0.0, (double)q};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) c[q] = MFMA_F64(a, b, c[q]);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) s += c[q][0] + c[q][1] + c[q][2] + c[q][3];
+  if (s == 123.456) sink[blockIdx.x * kThreads + l] = s;
+}
+
+}  // namespace
+
+// =======================================================================================
+// host side
+// =======================================================================================
+struct ldc_solver {
+  ldc_problem p;
+  int nt;            // T*T
+  int n_edge_blocks; // blocks of 4 edge nodes (tail case), else 0
+  int n_pedge_blocks;
+  int iters_per_graph;
+  hipGraphExec_t graph[2];   // [with_diagnostics]
+  hipStream_t capture_stream;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                         \
+  do {                                        \
+    hipError_t _e = (expr);                   \
+    if (_e != hipSuccess) return (int)_e;     \
+  } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+StageArgs make_stage_args(const ldc_solver* s, int k) {
+  const ldc_problem& p = s->p;
+  StageArgs a;
+  memset(&a, 0, sizeof(a));
+  a.M = p.M; a.LD = p.LD; a.T = p.T; a.tail = p.tail;
+  a.nu = p.nu; a.beta2 = p.beta2;
+  static const double alphas[4] = {0.25, 1.0 / 3.0, 0.5, 1.0};   // sg.py:430
+  a.alpha = alphas[k];
+  a.Dx = p.Dx; a.D2x = p.D2x; a.Dy = p.Dy; a.D2y = p.D2y; a.IxF = p.IxF; a.GxF = p.GxF;
+  a.U0 = p.U; a.V0 = p.V; a.P0 = p.P;
+  a.T1T = p.T1T; a.T2T = p.T2T; a.PX = p.PX; a.PY = p.PY;
+  a.ulid = p.ulid; a.wx = p.wx; a.wy = p.wy; a.scal = p.scal; a.ctrl = p.ctrl;
+  a.partials = p.partials;
+  // ping-pong: 0: S0 -> A, 1: A -> B, 2: B -> A, 3: A -> S0 (in place)
+  const double *in[4][4] = {{p.U, p.UT, p.V, p.VT}, {p.UA, p.UAT, p.VA, p.VAT},
+                            {p.UB, p.UBT, p.VB, p.VBT}, {p.UA, p.UAT, p.VA, p.VAT}};
+  double* out[4][4] = {{p.UA, p.UAT, p.VA, p.VAT}, {p.UB, p.UBT, p.VB, p.VBT},
+                       {p.UA, p.UAT, p.VA, p.VAT}, {p.U, p.UT, p.V, p.VT}};
+  a.Uin = in[k][0]; a.UinT = in[k][1]; a.Vin = in[k][2]; a.VinT = in[k][3];
+  a.Uout = out[k][0]; a.UoutT = out[k][1]; a.Vout = out[k][2]; a.VoutT = out[k][3];
+  a.Pout = (k == 3) ? p.P : nullptr;   // SG never consumes the stage pressures (quirk Q1)
+  return a;
+}
+
+int launch_stage(const ldc_solver* s, int k, hipStream_t st) {
+  const StageArgs a = make_stage_args(s, k);
+  const dim3 blk(kThreads);
+  if (k == 0) {
+    hipLaunchKernelGGL((stage_kernel<true, false, false>), dim3(s->nt), blk, 0, st, a);
+  } else if (k < 3) {
+    hipLaunchKernelGGL((stage_kernel<false, false, false>), dim3(s->nt), blk, 0, st, a);
+  } else {
+    hipLaunchKernelGGL((stage_kernel<false, true, false>), dim3(s->nt + s->n_edge_blocks), blk, 0, st, a);
+  }
+  return (int)hipGetLastError();
+}
+
+int launch_post(const ldc_solver* s, const double* P, int do_omega, int ignore_latch, hipStream_t st) {
+  const ldc_problem& p = s->p;
+  PostArgs a;
+  memset(&a, 0, sizeof(a));
+  a.M = p.M; a.LD = p.LD; a.T = p.T; a.tail = p.tail; a.do_omega = do_omega;
+  a.Dx = p.Dx; a.Dy = p.Dy; a.IyF = p.IyF; a.GyF = p.GyF;
+  a.U = p.U; a.V = p.V; a.VT = p.VT; a.P = P;
+  a.T1T = p.T1T; a.T2T = p.T2T; a.W = p.W; a.WT = p.WT; a.wx = p.wx; a.wy = p.wy;
+  a.ctrl = p.ctrl; a.partZ = p.partials + p.partials_stride; a.ignore_latch = ignore_latch;
+  int grid = s->nt + s->n_pedge_blocks;
+  if (do_omega) grid += s->nt + s->n_edge_blocks;
+  hipLaunchKernelGGL(post_kernel, dim3(grid), dim3(kThreads), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+int launch_palin(const ldc_solver* s, int ignore_latch, hipStream_t st) {
+  const ldc_problem& p = s->p;
+  PalinArgs a;
+  memset(&a, 0, sizeof(a));
+  a.M = p.M; a.LD = p.LD; a.T = p.T; a.tail = p.tail;
+  a.Dx = p.Dx; a.Dy = p.Dy; a.W = p.W; a.WT = p.WT; a.wx = p.wx; a.wy = p.wy;
+  a.ctrl = p.ctrl; a.partP = p.partials + 2 * p.partials_stride; a.ignore_latch = ignore_latch;
+  hipLaunchKernelGGL(palin_kernel, dim3(s->nt + s->n_edge_blocks), dim3(kThreads), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+FinalArgs make_final_args(const ldc_solver* s, int with_diag) {
+  const ldc_problem& p = s->p;
+  FinalArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nblk4 = s->nt + s->n_edge_blocks; a.nblkZ = a.nblk4; a.nblkP = a.nblk4;
+  a.with_diag = with_diag; a.warmup = p.warmup; a.nan_guard = p.nan_guard; a.rec_cap = p.rec_cap;
+  a.cfl = p.cfl; a.beta2 = p.beta2; a.nu = p.nu; a.hx = p.hx_min; a.hy = p.hy_min;
+  a.lid = p.lid_speed; a.tol = p.tol;
+  a.part4 = p.partials; a.partZ = p.partials + p.partials_stride; a.partP = p.partials + 2 * p.partials_stride;
+  a.scal = p.scal; a.ctrl = p.ctrl; a.rec = p.rec;
+  return a;
+}
+
+int launch_finalize(const ldc_solver* s, int with_diag, hipStream_t st) {
+  const FinalArgs a = make_final_args(s, with_diag);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kThreads), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+// one iteration of base.py:243-313 as launches on `st`
+int launch_iteration(const ldc_solver* s, int with_diag, hipStream_t st) {
+  int e;
+  for (int k = 0; k < 4; ++k)
+    if ((e = launch_stage(s, k, st)) != 0) return e;
+  if ((e = launch_post(s, s->p.P, with_diag, 0, st)) != 0) return e;
+  if (with_diag && (e = launch_palin(s, 0, st)) != 0) return e;
+  return launch_finalize(s, with_diag, st);
+}
+
+int build_graph(ldc_solver* s, int with_diag) {
+  if (s->capture_stream == nullptr) HIP_TRY(hipStreamCreateWithFlags(&s->capture_stream, hipStreamNonBlocking));
+  hipGraph_t g = nullptr;
+  HIP_TRY(hipStreamBeginCapture(s->capture_stream, hipStreamCaptureModeThreadLocal));
+  int e = 0;
+  for (int it = 0; it < s->iters_per_graph && e == 0; ++it) e = launch_iteration(s, with_diag, s->capture_stream);
+  hipError_t ce = hipStreamEndCapture(s->capture_stream, &g);
+  if (e != 0) { if (g) hipGraphDestroy(g); return e; }
+  if (ce != hipSuccess) return (int)ce;
+  hipError_t ie = hipGraphInstantiate(&s->graph[with_diag], g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  return (int)ie;
+}
+
+bool bad_ptr(const void* p) { return p == nullptr; }
+
+}  // namespace
+
+extern "C" {
+
+int ldc_version(void) { return LDC_ABI_VERSION; }
+
+const char* ldc_error_string(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case LDC_E_ARG: return "ldc: invalid argument (null pointer or inconsistent geometry)";
+    case LDC_E_STATE: return "ldc: invalid solver handle/state";
+    case LDC_E_NODEVICE: return "ldc: no gfx950 HIP device";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "ldc: unknown error";
+  }
+}
+
+int ldc_device_check(char* arch, int arch_len) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return LDC_E_NODEVICE;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  if (arch && arch_len > 0) { strncpy(arch, prop.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+  return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 0 : LDC_E_NODEVICE;
+}
+
+int ldc_solver_create(const ldc_problem* d, ldc_solver** out) {
+  if (!d || !out) return LDC_E_ARG;
+  if (d->M < 4 || d->T < 1 || d->T != (d->M - 1 + 15) / 16) return LDC_E_ARG;
+  if (d->LD % 16 != 0 || d->LD < 16 * d->T + 16 || d->LD < d->M) return LDC_E_ARG;
+  if (d->tail != ((16 * d->T == d->M - 1) ? 1 : 0)) return LDC_E_ARG;
+  if (d->rec_cap < 1 || d->stage_pressure != 0) return LDC_E_ARG;
+  const void* req[] = {d->Dx, d->D2x, d->Dy, d->D2y, d->IxF, d->GxF, d->IyF, d->GyF, d->wx, d->wy, d->ulid,
+                       d->U, d->UT, d->V, d->VT, d->P, d->UA, d->UAT, d->VA, d->VAT, d->UB, d->UBT, d->VB,
+                       d->VBT, d->T1T, d->T2T, d->PX, d->PY, d->W, d->WT, d->partials, d->scal, d->ctrl, d->rec};
+  for (const void* q : req) if (bad_ptr(q)) return LDC_E_ARG;
+  ldc_solver* s = new (std::nothrow) ldc_solver;
+  if (!s) return LDC_E_STATE;
+  s->p = *d;
+  s->nt = d->T * d->T;
+  s->n_edge_blocks = d->tail ? (2 * d->M - 1 + kWaves - 1) / kWaves : 0;
+  s->n_pedge_blocks = d->tail ? (d->M + kWaves - 1) / kWaves : 0;
+  if (d->partials_stride < (int64_t)(s->nt + s->n_edge_blocks) * LDC_NPART) { delete s; return LDC_E_ARG; }
+  s->iters_per_graph = 32;
+  s->graph[0] = s->graph[1] = nullptr;
+  s->capture_stream = nullptr;
+  *out = s;
+  return 0;
+}
+
+int ldc_solver_destroy(ldc_solver* s) {
+  if (!s) return LDC_E_STATE;
+  for (int q = 0; q < 2; ++q) if (s->graph[q]) hipGraphExecDestroy(s->graph[q]);
+  if (s->capture_stream) hipStreamDestroy(s->capture_stream);
+  delete s;
+  return 0;
+}
+
+int ldc_solver_set_graph_iters(ldc_solver* s, int n) {
+  if (!s || n < 1 || n > 4096) return LDC_E_ARG;
+  if (s->graph[0] || s->graph[1]) return LDC_E_STATE;
+  s->iters_per_graph = n;
+  return 0;
+}
+
+int ldc_stage(ldc_solver* s, int k, void* stream) {
+  if (!s) return LDC_E_STATE;
+  if (k < 0 || k > 3) return LDC_E_ARG;
+  return launch_stage(s, k, as_stream(stream));
+}
+
+int ldc_pressure_transform(ldc_solver* s, int which, void* stream) {
+  if (!s) return LDC_E_STATE;
+  const double* P = which == 0 ? s->p.P : which == 1 ? s->p.PA : which == 2 ? s->p.PB : nullptr;
+  if (!P) return LDC_E_ARG;
+  return launch_post(s, P, 0, 1, as_stream(stream));
+}
+
+int ldc_diagnostics(ldc_solver* s, void* stream) {
+  if (!s) return LDC_E_STATE;
+  int e = launch_post(s, s->p.P, 1, 1, as_stream(stream));
+  if (e) return e;
+  return launch_palin(s, 1, as_stream(stream));
+}
+
+int ldc_finalize(ldc_solver* s, int with_diag, void* stream) {
+  if (!s) return LDC_E_STATE;
+  return launch_finalize(s, with_diag ? 1 : 0, as_stream(stream));
+}
+
+int ldc_prime(ldc_solver* s, void* stream) {
+  if (!s) return LDC_E_STATE;
+  int e = launch_post(s, s->p.P, 0, 1, as_stream(stream));
+  if (e) return e;
+  const FinalArgs a = make_final_args(s, 0);
+  hipLaunchKernelGGL(prime_kernel, dim3(1), dim3(kThreads), 0, as_stream(stream), s->p.U, s->p.V,
+                     s->p.LD * s->p.LD, a);
+  return (int)hipGetLastError();
+}
+
+int ldc_solver_enqueue(ldc_solver* s, int n_iters, int with_diag, void* stream) {
+  if (!s) return LDC_E_STATE;
+  if (n_iters < 0) return LDC_E_ARG;
+  with_diag = with_diag ? 1 : 0;
+  hipStream_t st = as_stream(stream);
+  int left = n_iters;
+  if (left >= s->iters_per_graph) {
+    if (!s->graph[with_diag]) { int e = build_graph(s, with_diag); if (e) return e; }
+    while (left >= s->iters_per_graph) {
+      HIP_TRY(hipGraphLaunch(s->graph[with_diag], st));
+      left -= s->iters_per_graph;
+    }
+  }
+  for (; left > 0; --left) { int e = launch_iteration(s, with_diag, st); if (e) return e; }
+  return 0;
+}
+
+int ldc_residual_debug(ldc_solver* s, int which, double* const out[11], void* stream) {
+  if (!s || !out) return LDC_E_ARG;
+  for (int q = 0; q < 11; ++q) if (!out[q]) return LDC_E_ARG;
+  if (which < 0 || which > 2) return LDC_E_ARG;
+  hipStream_t st = as_stream(stream);
+  int e = launch_post(s, s->p.P, 0, 1, st);   // SG differentiates p^n whatever the stage (Q1)
+  if (e) return e;
+  StageArgs a = make_stage_args(s, which == 0 ? 0 : which == 1 ? 1 : 2);
+  for (int q = 0; q < 11; ++q) a.dump[q] = out[q];
+  hipLaunchKernelGGL((stage_kernel<true, false, true>), dim3(s->nt + s->n_edge_blocks), dim3(kThreads), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+int ldc_gemm_nt(const double* A, const double* B, double* C, int R16, int K16, int LD, int transpose_out,
+                int scale_mode, const double* lam_r, const double* lam_c, void* stream) {
+  if (!A || !B || !C || R16 < 1 || K16 < 1 || LD % 16 != 0 || LD < 16 * R16 || LD < 16 * K16) return LDC_E_ARG;
+  if (scale_mode != 0 && (scale_mode != 1 || !lam_r || !lam_c)) return LDC_E_ARG;
+  GemmArgs a = {A, B, C, R16, K16, LD, transpose_out, scale_mode, lam_r, lam_c};
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3(R16, R16), dim3(kThreads), 0, as_stream(stream), a);
+  return (int)hipGetLastError();
+}
+
+int ldc_poisson_fastdiag(const double* Qx, const double* Qxinv, const double* Qy, const double* Qyinv,
+                         const double* lamx, const double* lamy, const double* F, double* w0, double* w1,
+                         double* Psi, int Mi, int LD, void* stream) {
+  if (!Qx || !Qxinv || !Qy || !Qyinv || !lamx || !lamy || !F || !w0 || !w1 || !Psi || Mi < 1) return LDC_E_ARG;
+  const int R = (Mi + 15) / 16;
+  int e;
+  // X = F Qyinv^T, stored transposed:           w0[j][i] = sum_k F[i][k] Qyinv[j][k]
+  if ((e = ldc_gemm_nt(F, Qyinv, w0, R, R, LD, 1, 0, nullptr, nullptr, stream)) != 0) return e;
+  // Phat = Qxinv X / (lamx_i + lamy_j):         w1[i][j] = sum_k Qxinv[i][k] w0[j][k]
+  if ((e = ldc_gemm_nt(Qxinv, w0, w1, R, R, LD, 0, 1, lamx, lamy, stream)) != 0) return e;
+  // Y = Phat Qy^T, stored transposed:           w0[j][i] = sum_k w1[i][k] Qy[j][k]
+  if ((e = ldc_gemm_nt(w1, Qy, w0, R, R, LD, 1, 0, nullptr, nullptr, stream)) != 0) return e;
+  // Psi = Qx Y:                                 Psi[i][j] = sum_k Qx[i][k] w0[j][k]
+  return ldc_gemm_nt(Qx, w0, Psi, R, R, LD, 0, 0, nullptr, nullptr, stream);
+}
+
+int ldc_vortex_extrema(const double* Psi, const double* W, const double* x, const double* y, int M, int LD,
+                       double* out_val, int32_t* out_idx, void* stream) {
+  if (!Psi || !W || !x || !y || !out_val || !out_idx || M < 2 || LD < M) return LDC_E_ARG;
+  hipLaunchKernelGGL(extrema_kernel, dim3(1), dim3(1024), 0, as_stream(stream), Psi, W, x, y, M, LD, out_val, out_idx);
+  return (int)hipGetLastError();
+}
+
+int ldc_mfma_selftest(const double* A, const double* B, double* D, void* stream) {
+  if (!A || !B || !D) return LDC_E_ARG;
+  hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, as_stream(stream), A, B, D);
+  return (int)hipGetLastError();
+}
+
+int ldc_mfma_peak(double* sink, int iters, int grid, void* stream) {
+  if (!sink || iters < 1 || grid < 1) return LDC_E_ARG;
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(grid), dim3(kThreads), 0, as_stream(stream), sink, iters);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+"""Modal interpolation on collocation nodes -- the centreline-extraction recipe.
+
+Contract: reference src/solvers/spectral/basis/polynomial.py:15-73 (Jacobi recurrence),
+:398-477 (``spectral_interpolate``), used by the Ghia comparison
+(src/shared/plotting/ldc/validation.py:297-322).  Post-processing, host side.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def jacobi_poly(xs, alpha: float, beta: float, N: int) -> np.ndarray:
+    """P_N^{(alpha,beta)} at xs by the three-term recurrence."""
+    xs = np.asarray(xs, dtype=float)
+    older = np.ones_like(xs)
+    if N == 0:
+        return older
+    newer = 0.5 * (alpha - beta + (alpha + beta + 2) * xs)
+    ab = alpha + beta
+    for m in range(1, N):
+        s = 2 * m + ab
+        lo = 2 * (m + alpha) * (m + beta) / ((s + 1) * s)
+        mid = (alpha**2 - beta**2) / ((s + 2) * s) if alpha != beta else 0.0
+        hi = 2 * (m + 1) * (m + ab + 1) / ((s + 2) * (s + 1))
+        older, newer = newer, ((mid + xs) * newer - lo * older) / hi
+    return newer
+
+
+def vandermonde(xs, alpha: float, beta: float, ncols: int | None = None) -> np.ndarray:
+    ncols = len(xs) if ncols is None else ncols
+    return np.stack([jacobi_poly(xs, alpha, beta, n) for n in range(ncols)], axis=1)
+
+
+def spectral_interpolate(x_nodes, f_values, x_eval, basis: str = "legendre") -> np.ndarray:
+    """Evaluate the interpolating polynomial of (x_nodes, f_values) at x_eval."""
+    table = {"legendre": (0.0, 0.0), "chebyshev": (-0.5, -0.5)}
+    if basis.lower() not in table:
+        raise ValueError(f"Unknown basis: {basis}. Use 'legendre' or 'chebyshev'.")
+    alpha, beta = table[basis.lower()]
+    x_nodes = np.asarray(x_nodes, dtype=float)
+    x_eval = np.asarray(x_eval, dtype=float)
+    lo, hi = x_nodes.min(), x_nodes.max()
+    if not (np.isclose(lo, -1.0) and np.isclose(hi, 1.0)):
+        x_nodes = 2.0 * (x_nodes - lo) / (hi - lo) - 1.0
+        x_eval = 2.0 * (x_eval - lo) / (hi - lo) - 1.0
+    modal = np.linalg.solve(vandermonde(x_nodes, alpha, beta), f_values)
+    return vandermonde(x_eval, alpha, beta, ncols=len(x_nodes)) @ modal

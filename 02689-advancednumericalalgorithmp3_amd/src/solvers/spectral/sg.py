@@ -1,0 +1,400 @@
+"""Single-grid Chebyshev P_N-P_{N-2} artificial-compressibility solver on MI355X.
+
+Plugin surface: ``solvers.spectral.sg.SGSolver(**cfg.solver)`` exactly as the reference's
+Hydra ``_target_`` (conf/solver/spectral/sg.yaml:3; reference class
+src/solvers/spectral/sg.py:29).  Same constructor keys, same ``solve()/metrics/fields/
+time_series``; the arithmetic of ``step()`` (sg.py:410-449), the per-iteration norms and
+E/Z/P (base.py:250-276) and the psi post-processing (sg.py:556-709) run in hand-written
+gfx950 kernels behind ``libldc_hip.so``; this file only builds operators with NumPy, owns
+the device tensors and polls a latch.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+
+import numpy as np
+
+from ..base import LidDrivenCavitySolver
+from ..datastructures import SpectralParameters
+from . import ldc_lib as L
+from .basis.spectral import ChebyshevLobattoBasis, inner_to_full_interpolation
+from .operators.corner import create_corner_treatment
+
+log = logging.getLogger(__name__)
+
+_MAT_NAMES = ("Dx", "D2x", "Dy", "D2y", "IxF", "GxF", "IyF", "GyF",
+              "U", "UT", "V", "VT", "P", "UA", "UAT", "VA", "VAT", "PA",
+              "UB", "UBT", "VB", "VBT", "PB", "T1T", "T2T", "PX", "PY", "W", "WT",
+              "S0", "S1", "S2", "S3", "S4", "S5", "S6", "S7", "S8", "S9", "S10")   # S*: scratch
+_DEBUG_KEYS = ("du_dx", "du_dy", "dv_dx", "dv_dy", "lap_u", "lap_v", "dp_dx", "dp_dy", "R_u", "R_v", "R_p")
+
+
+class _ArraysView:
+    """``solver.arrays.u / .v / .p`` as host copies of the device state (flat, like the
+    reference's SpectralSolverFields); assigning uploads."""
+
+    def __init__(self, owner):
+        object.__setattr__(self, "_o", owner)
+
+    def __getattr__(self, name):
+        o = self._o
+        if name in ("u", "v"):
+            return o._download_full("U" if name == "u" else "V").ravel()
+        if name == "p":
+            return o._download_full("P")[1:-1, 1:-1].ravel().copy()
+        if name in ("R_u", "R_v", "R_p") or name in _DEBUG_KEYS:
+            return o.residual_fields()[name]
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        o = self._o
+        if name not in ("u", "v", "p"):
+            raise AttributeError(name)
+        cur = {"u": None, "v": None, "p": None}
+        cur[name] = np.asarray(value, dtype=float)
+        o.set_state(**cur)
+
+
+class SGSolver(LidDrivenCavitySolver):
+    Parameters = SpectralParameters
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        p = self.params
+        kind = p.basis_type.lower()
+        if kind == "chebyshev":
+            self.basis_x = ChebyshevLobattoBasis(domain=(0.0, p.Lx))
+            self.basis_y = ChebyshevLobattoBasis(domain=(0.0, p.Ly))
+        elif kind == "legendre":
+            raise NotImplementedError(
+                "basis_type='legendre' is outside the MI355X hot path; use 'chebyshev' "
+                "(conf/solver/spectral/sg.yaml)")
+        else:
+            raise ValueError(f"Unknown basis_type: {p.basis_type}. Use 'legendre' or 'chebyshev'")
+        if p.nx != p.ny:
+            raise NotImplementedError("the HIP path needs nx == ny (all reference configs set both to N)")
+        self.corner_treatment = create_corner_treatment(
+            method=p.corner_treatment, smoothing_width=p.corner_smoothing)
+
+        self._build_operators()
+        self.shape_full = (self.M, self.M)
+        self.shape_inner = (self.M - 2, self.M - 2)
+        self._init_fields(x=self.x_full.ravel(), y=self.y_full.ravel())
+        self._alloc_device()
+        self.arrays = _ArraysView(self)
+        self._handle = None
+        self._handle_tol = None
+        self._eig = None
+        self.reset_state()
+
+    # ------------------------------------------------------------------ host-side setup
+    def _build_operators(self):
+        p = self.params
+        M = p.nx + 1
+        self.M = M
+        x = self.basis_x.nodes(M)
+        y = self.basis_y.nodes(M)
+        self.x_nodes, self.y_nodes = x, y
+        self.x_full, self.y_full = np.meshgrid(x, y, indexing="ij")
+        self.dx_min = float(np.min(np.diff(x)))
+        self.dy_min = float(np.min(np.diff(y)))
+        self.Dx_1d = self.basis_x.diff_matrix(x)
+        self.Dy_1d = self.basis_y.diff_matrix(y)
+        self.Dxx_1d = self.Dx_1d @ self.Dx_1d
+        self.Dyy_1d = self.Dy_1d @ self.Dy_1d
+        self.Interp_x = inner_to_full_interpolation(x[1:-1], x)
+        self.Interp_y = inner_to_full_interpolation(y[1:-1], y)
+        self.w_x = self.basis_x.quadrature_weights(M)
+        self.w_y = self.basis_y.quadrature_weights(M)
+        u_lid, _ = self.corner_treatment.get_lid_velocity(
+            x, np.full_like(x, p.Ly), lid_velocity=p.lid_velocity, Lx=p.Lx, Ly=p.Ly)
+        self.u_lid = u_lid
+        # geometry of the MFMA tiling
+        self.T = (M - 1 + 15) // 16
+        self.tail = 1 if 16 * self.T == M - 1 else 0
+        self.LD = 16 * self.T + 16
+
+    def _alloc_device(self):
+        import torch
+        L.require_device()
+        dev = torch.device(self.params.device)
+        self.device = dev
+        LD, M = self.LD, self.M
+        self._mats = torch.zeros((len(_MAT_NAMES), LD, LD), dtype=torch.float64, device=dev)
+        self.d = {n: self._mats[k] for k, n in enumerate(_MAT_NAMES)}
+        self._vecs = torch.zeros((8, LD), dtype=torch.float64, device=dev)
+        for k, n in enumerate(("wx", "wy", "ulid", "x", "y", "lamx", "lamy")):
+            self.d[n] = self._vecs[k]
+        nt = self.T * self.T
+        n_edge = (2 * M - 1 + 3) // 4 if self.tail else 0
+        self._part_stride = (nt + n_edge) * L.NPART
+        self.d["partials"] = torch.zeros(4 * self._part_stride, dtype=torch.float64, device=dev)
+        self.d["scal"] = torch.zeros(L.SCAL_LEN, dtype=torch.float64, device=dev)
+        self.d["ctrl"] = torch.zeros(L.CTRL_LEN, dtype=torch.int32, device=dev)
+        self.rec_cap = max(1, int(self.params.check_every))
+        self.d["rec"] = torch.zeros((self.rec_cap, L.REC_LEN), dtype=torch.float64, device=dev)
+        self.d["ext_val"] = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.d["ext_idx"] = torch.zeros(8, dtype=torch.int32, device=dev)
+
+        def up(name, a):
+            pad = np.zeros((LD, LD))
+            pad[: a.shape[0], : a.shape[1]] = a
+            self.d[name].copy_(torch.from_numpy(pad))
+
+        IxF = np.zeros((M, M)); IxF[:, 1:-1] = self.Interp_x
+        IyF = np.zeros((M, M)); IyF[:, 1:-1] = self.Interp_y
+        for name, a in (("Dx", self.Dx_1d), ("D2x", self.Dxx_1d), ("Dy", self.Dy_1d), ("D2y", self.Dyy_1d),
+                        ("IxF", IxF), ("GxF", self.Dx_1d @ IxF), ("IyF", IyF), ("GyF", self.Dy_1d @ IyF)):
+            up(name, a)
+        for name, v in (("wx", self.w_x), ("wy", self.w_y), ("ulid", self.u_lid),
+                        ("x", self.x_nodes), ("y", self.y_nodes)):
+            pad = np.zeros(LD); pad[:M] = v
+            self.d[name].copy_(torch.from_numpy(pad))
+
+    # ------------------------------------------------------------------ state transfer
+    def _download_full(self, name: str) -> np.ndarray:
+        import torch
+        torch.cuda.synchronize(self.device)
+        return self.d[name][: self.M, : self.M].cpu().numpy()
+
+    def _upload_full(self, name: str, a2d: np.ndarray, transposed_name: str = None):
+        import torch
+        pad = np.zeros((self.LD, self.LD))
+        pad[: a2d.shape[0], : a2d.shape[1]] = a2d
+        t = torch.from_numpy(pad).to(self.device)
+        self.d[name].copy_(t)
+        if transposed_name:
+            self.d[transposed_name].copy_(t.t())
+
+    def set_state(self, u=None, v=None, p=None):
+        """Upload (flat or 2-D) host arrays; p lives on the (N-1)^2 inner grid."""
+        M = self.M
+        if u is not None:
+            self._upload_full("U", np.asarray(u, float).reshape(M, M), "UT")
+        if v is not None:
+            self._upload_full("V", np.asarray(v, float).reshape(M, M), "VT")
+        if p is not None:
+            full = np.zeros((M, M))
+            full[1:-1, 1:-1] = np.asarray(p, float).reshape(M - 2, M - 2)
+            self._upload_full("P", full)
+        # stage buffers carry the same boundary row/column (never rewritten when `tail`)
+        for src, dsts in (("U", ("UA", "UB")), ("UT", ("UAT", "UBT")), ("V", ("VA", "VB")),
+                          ("VT", ("VAT", "VBT")), ("P", ("PA", "PB"))):
+            for dn in dsts:
+                self.d[dn].copy_(self.d[src])
+        self._primed = False
+
+    def reset_state(self):
+        """Fluid at rest with the regularised lid (reference sg.py:76-98)."""
+        M = self.M
+        u = np.zeros((M, M))
+        u[:, -1] = self.u_lid
+        self.set_state(u=u, v=np.zeros((M, M)), p=np.zeros((M - 2, M - 2)))
+        self.d["ctrl"].zero_()
+        self.d["scal"].zero_()
+
+    # ------------------------------------------------------------------ C-ABI plumbing
+    def _problem(self, tol: float) -> L.Problem:
+        p = self.params
+        pr = L.Problem()
+        pr.M, pr.LD, pr.T, pr.tail = self.M, self.LD, self.T, self.tail
+        pr.nu, pr.beta2, pr.cfl = 1.0 / p.Re, p.beta_squared, p.CFL
+        pr.hx_min, pr.hy_min, pr.lid_speed, pr.tol = self.dx_min, self.dy_min, p.lid_velocity, tol
+        pr.warmup, pr.nan_guard, pr.stage_pressure, pr.rec_cap = 10, int(bool(p.nan_guard)), 0, self.rec_cap
+        for name, _ in L.Problem._fields_:
+            if name in self.d and name != "partials_stride":
+                setattr(pr, name, self.d[name].data_ptr())
+        pr.partials_stride = self._part_stride
+        return pr
+
+    def _ensure_handle(self, tol: float):
+        if self._handle is not None and self._handle_tol == tol:
+            return
+        self.close()
+        h = C.c_void_p()
+        pr = self._problem(tol)
+        L.check(L.lib().ldc_solver_create(C.byref(pr), C.byref(h)), "ldc_solver_create")
+        L.check(L.lib().ldc_solver_set_graph_iters(h, int(self.params.graph_iters)), "ldc_solver_set_graph_iters")
+        self._handle, self._handle_tol = h, tol
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None:
+            import torch
+            torch.cuda.synchronize(self.device)
+            L.lib().ldc_solver_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _prime(self):
+        if not self._primed:
+            L.check(L.lib().ldc_prime(self._handle, L.stream_ptr()), "ldc_prime")
+            self._primed = True
+
+    # ------------------------------------------------------------------ driver hooks
+    def _begin(self, tolerance: float, restart: bool = True):
+        """Every solve() counts iterations from 0 (warm-up included), like base.py:243."""
+        self._ensure_handle(float(tolerance))
+        if restart:
+            self.d["ctrl"].zero_()
+        self._prime()
+
+    def _advance(self, n_iters: int):
+        import torch
+        ctrl0 = self.d["ctrl"].cpu().numpy()
+        start = int(ctrl0[L.CTRL_ITER])
+        n_iters = min(int(n_iters), self.rec_cap)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ldc_solver_enqueue(self._handle, n_iters, int(bool(self.params.diagnostics)),
+                                               L.stream_ptr()), "ldc_solver_enqueue")
+            torch.cuda.synchronize(self.device)
+        ctrl = self.d["ctrl"].cpu().numpy()
+        end, done = int(ctrl[L.CTRL_ITER]), int(ctrl[L.CTRL_DONE])
+        ring = self.d["rec"].cpu().numpy()
+        rows = ring[np.arange(start, end) % self.rec_cap]
+        return rows, done, end
+
+    def step(self):
+        """One pseudo-time step (4 RK stages + BCs) and the reductions that give the next dt."""
+        self._begin(self.params.tolerance if self._handle_tol is None else self._handle_tol, restart=False)
+        self._advance_raw(1, diagnostics=False)
+        return self.arrays.u, self.arrays.v, self.arrays.p
+
+    def _advance_raw(self, n, diagnostics):
+        keep = self.params.diagnostics
+        self.params.diagnostics = diagnostics
+        try:
+            return self._advance(n)
+        finally:
+            self.params.diagnostics = keep
+
+    def run_iterations(self, n: int, diagnostics: bool = True, tolerance: float = 0.0,
+                       restart: bool = False) -> np.ndarray:
+        """Run n more iterations (tolerance 0 = no convergence stop); returns their records."""
+        self._begin(tolerance, restart=restart)
+        out, left = [], int(n)
+        while left > 0:
+            rows, done, _ = self._advance_raw(min(left, self.rec_cap), diagnostics)
+            out.append(rows)
+            left -= len(rows)
+            if done or len(rows) == 0:
+                break
+        return np.concatenate(out, axis=0) if out else np.zeros((0, 8))
+
+    # ------------------------------------------------------------------ results
+    def _finalize_fields(self):
+        u, v, pf = self._download_full("U"), self._download_full("V"), self._download_full("P")
+        self.fields.u[:] = u.ravel()
+        self.fields.v[:] = v.ravel()
+        self.fields.p[:] = self._extrapolate_to_full_grid(pf[1:-1, 1:-1]).ravel()
+
+    def _extrapolate_to_full_grid(self, inner: np.ndarray) -> np.ndarray:
+        """Output pressure: linear extrapolation to the edges (quirk Q5; reference sg.py:144-179)."""
+        f = np.zeros(self.shape_full)
+        f[1:-1, 1:-1] = inner
+        f[0, 1:-1] = 2 * f[1, 1:-1] - f[2, 1:-1]
+        f[-1, 1:-1] = 2 * f[-2, 1:-1] - f[-3, 1:-1]
+        f[1:-1, 0] = 2 * f[1:-1, 1] - f[1:-1, 2]
+        f[1:-1, -1] = 2 * f[1:-1, -2] - f[1:-1, -3]
+        for (a, b), (n1, n2) in ((((0, 0)), ((0, 1), (1, 0))), ((0, -1), ((0, -2), (1, -1))),
+                                 ((-1, 0), ((-1, 1), (-2, 0))), ((-1, -1), ((-1, -2), (-2, -1)))):
+            f[a, b] = 0.5 * (f[n1] + f[n2])
+        return f
+
+    def residual_fields(self, which: int = 0) -> dict:
+        """All intermediates of one residual evaluation (parity tests; reference sg.py:278-346)."""
+        import torch
+        self._ensure_handle(self.params.tolerance if self._handle_tol is None else self._handle_tol)
+        outs = [self.d[f"S{k}"] for k in range(11)]
+        for t in outs:
+            t.zero_()
+        arr = (C.c_void_p * 11)(*[t.data_ptr() for t in outs])
+        L.check(L.lib().ldc_residual_debug(self._handle, which, arr, L.stream_ptr()), "ldc_residual_debug")
+        torch.cuda.synchronize(self.device)
+        M = self.M
+        res = {}
+        for k, key in enumerate(_DEBUG_KEYS):
+            a = outs[k][:M, :M].cpu().numpy()
+            res[key] = a[1:-1, 1:-1].ravel().copy() if key == "R_p" else a.ravel()
+        return res
+
+    # ---- vorticity / stream function / vortices (reference sg.py:510-743) --------------------
+    def _compute_vorticity(self) -> np.ndarray:
+        import torch
+        self._ensure_handle(self.params.tolerance if self._handle_tol is None else self._handle_tol)
+        L.check(L.lib().ldc_diagnostics(self._handle, L.stream_ptr()), "ldc_diagnostics")
+        torch.cuda.synchronize(self.device)
+        return self._download_full("W").ravel()
+
+    def _eigenbasis(self):
+        """Eigen-decomposition of the interior second-derivative blocks (done once, host)."""
+        if self._eig is None:
+            import torch
+            out = {}
+            for tag, D2 in (("x", self.Dxx_1d), ("y", self.Dyy_1d)):
+                lam, Q = np.linalg.eig(D2[1:-1, 1:-1])
+                if np.max(np.abs(lam.imag)) > 1e-8 * np.max(np.abs(lam.real)):
+                    raise RuntimeError("interior D2 block has complex eigenvalues")
+                lam, Q = lam.real, Q.real
+                out[tag] = (lam, Q, np.linalg.inv(Q))
+            names = {"Qx": out["x"][1], "Qxi": out["x"][2], "Qy": out["y"][1], "Qyi": out["y"][2]}
+            self._eig_t = torch.zeros((4, self.LD, self.LD), dtype=torch.float64, device=self.device)
+            for k, (n, a) in enumerate(names.items()):
+                pad = np.zeros((self.LD, self.LD)); pad[: a.shape[0], : a.shape[1]] = a
+                self._eig_t[k].copy_(torch.from_numpy(pad))
+            for n, lam in (("lamx", out["x"][0]), ("lamy", out["y"][0])):
+                pad = np.full(self.LD, -1.0); pad[: lam.size] = lam      # padding: any non-zero sum
+                self.d[n].copy_(torch.from_numpy(pad))
+            self._eig = out
+        return self._eig_t
+
+    def _compute_streamfunction(self):
+        """psi from lap(psi) = -omega, psi = 0 on the walls, by fast diagonalisation on the GPU."""
+        import torch
+        Q = self._eigenbasis()
+        self._compute_vorticity()
+        M, Mi = self.M, self.M - 2
+        F, w0, w1, Psi = self.d["S0"], self.d["S1"], self.d["S2"], self.d["S3"]
+        F.zero_()
+        F[:Mi, :Mi] = -self.d["W"][1: M - 1, 1: M - 1]
+        L.check(L.lib().ldc_poisson_fastdiag(
+            Q[0].data_ptr(), Q[1].data_ptr(), Q[2].data_ptr(), Q[3].data_ptr(),
+            self.d["lamx"].data_ptr(), self.d["lamy"].data_ptr(), F.data_ptr(), w0.data_ptr(),
+            w1.data_ptr(), Psi.data_ptr(), Mi, self.LD, L.stream_ptr()), "ldc_poisson_fastdiag")
+        full = self.d["S4"]
+        full.zero_()
+        full[1: M - 1, 1: M - 1] = Psi[:Mi, :Mi]
+        torch.cuda.synchronize(self.device)
+        return full[:M, :M].cpu().numpy(), self.x_full, self.y_full
+
+    def compute_vortex_metrics(self) -> dict:
+        import torch
+        self._compute_streamfunction()          # leaves psi in S4 and omega in W
+        L.check(L.lib().ldc_vortex_extrema(
+            self.d["S4"].data_ptr(), self.d["W"].data_ptr(), self.d["x"].data_ptr(), self.d["y"].data_ptr(),
+            self.M, self.LD, self.d["ext_val"].data_ptr(), self.d["ext_idx"].data_ptr(), L.stream_ptr()),
+            "ldc_vortex_extrema")
+        torch.cuda.synchronize(self.device)
+        val = self.d["ext_val"].cpu().numpy()
+        idx = self.d["ext_idx"].cpu().numpy()
+        W = self.d["W"].cpu().numpy()
+        at = lambda k: divmod(int(idx[k]), self.LD)          # noqa: E731
+        x, y = self.x_nodes, self.y_nodes
+        i, j = at(0)
+        out = dict(psi_min=float(val[0]), psi_min_x=float(x[i]), psi_min_y=float(y[j]),
+                   omega_center=float(W[i, j]))
+        i, j = at(1)
+        out.update(omega_max=float(val[1]), omega_max_x=float(x[i]), omega_max_y=float(y[j]))
+        for k, name in ((2, "BR"), (3, "BL"), (4, "TL")):
+            i, j = at(k)
+            if val[k] > 0:
+                vals = (float(val[k]), float(W[i, j]), float(x[i]), float(y[j]))
+            else:
+                vals = (0.0, 0.0, 0.0, 0.0)
+            out[f"psi_{name}"], out[f"omega_{name}"], out[f"psi_{name}_x"], out[f"psi_{name}_y"] = vals
+        return out

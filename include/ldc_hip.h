@@ -1,0 +1,175 @@
+/*
+ * ldc_hip.h -- C ABI of libldc_hip.so: the MI355X (gfx950) hot path of the Chebyshev
+ * P_N-P_{N-2} artificial-compressibility lid-driven-cavity solver.
+ *
+ * The reference has no FFI: its plugin boundary is the Python class
+ * `solvers.spectral.sg.SGSolver` (reference src/solvers/spectral/sg.py:29) driven by
+ * `LidDrivenCavitySolver.solve` (src/solvers/base.py:202).  This header is the boundary a
+ * maintainer binds underneath that class (ctypes stub: INTEGRATION.md).  Each entry point
+ * names the reference lines whose work it replaces.
+ *
+ * Conventions
+ *  - every pointer in `ldc_problem` is a DEVICE pointer into caller-owned memory
+ *    (torch.float64 / torch.int32 tensors on the host side); the library allocates no
+ *    device memory and keeps no globals.  A solver handle owns only its captured
+ *    hipGraph executables.
+ *  - all 2-D arrays are row-major LD x LD doubles, zero padded, element [ix][iy]
+ *    (reference sg.py:108, indexing="ij"); LD is a multiple of 16 and >= 16*T + 16.
+ *  - "transposed copy" XT means XT[iy][ix] = X[ix][iy]; the kernels keep both so that
+ *    every MFMA operand is a contiguous 32-byte run per lane.
+ *  - functions return 0 on success, a negative LDC_E_* code for argument errors or a
+ *    positive hipError_t.  Nothing throws; nothing synchronises unless stated.
+ *  - `stream` is a hipStream_t passed as void*.
+ */
+#ifndef LDC_HIP_H
+#define LDC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDC_ABI_VERSION 1
+
+#define LDC_E_ARG      (-1)  /* null pointer / inconsistent geometry */
+#define LDC_E_STATE    (-2)  /* handle not valid for the call */
+#define LDC_E_NODEVICE (-3)  /* no HIP device / wrong architecture */
+
+/* slots of one history record written per iteration (ldc_problem.rec) */
+enum {
+  LDC_REC_REL = 0,  /* max(|du|/(|u_prev|+1e-12), same for v)       base.py:250-258 */
+  LDC_REC_RU  = 1,  /* ||R_u||_2 of the stage-4 residual, all nodes  sg.py:463-473  */
+  LDC_REC_RV  = 2,
+  LDC_REC_RP  = 3,
+  LDC_REC_E   = 4,  /* kinetic energy                                sg.py:495-508  */
+  LDC_REC_Z   = 5,  /* enstrophy                                     sg.py:524-533  */
+  LDC_REC_P   = 6,  /* palinstrophy                                  sg.py:535-550  */
+  LDC_REC_DT  = 7,  /* pseudo time step used by this iteration       sg.py:387-408  */
+  LDC_REC_LEN = 8
+};
+
+/* ctrl[] (int32) slots */
+enum {
+  LDC_CTRL_DONE      = 0, /* latch: 1 converged, 2 non-finite; later launches are no-ops */
+  LDC_CTRL_ITER      = 1, /* completed iterations                                       */
+  LDC_CTRL_LEN       = 8
+};
+
+/* scal[] (double) slots */
+enum {
+  LDC_SCAL_DT   = 0,  /* step for the NEXT iteration (device-resident, sg.py:427)       */
+  LDC_SCAL_UMAX = 1,
+  LDC_SCAL_VMAX = 2,
+  LDC_SCAL_LEN  = 8
+};
+
+#define LDC_NPART 12   /* doubles per work-group in `partials` */
+
+typedef struct ldc_problem {
+  /* geometry */
+  int32_t M;      /* nodes per axis, N+1                                               */
+  int32_t LD;     /* leading dimension of every padded array                           */
+  int32_t T;      /* 16x16 tiles per axis done on MFMA: ceil((M-1)/16)                 */
+  int32_t tail;   /* 1 when 16*T == M-1: index M-1 is handled by rank-1/edge paths     */
+  /* physics / control (reference conf/solver/spectral/sg.yaml, conf/config.yaml)      */
+  double nu;          /* 1/Re                                                          */
+  double beta2;       /* beta_squared                                                  */
+  double cfl;         /* CFL                                                           */
+  double hx_min, hy_min; /* min node spacing, sg.py:118-119                            */
+  double lid_speed;   /* lid_velocity (lower bound of u_max, sg.py:396)                */
+  double tol;         /* convergence tolerance on LDC_REC_REL                          */
+  int32_t warmup;     /* iterations without convergence test (10, base.py:264,283)     */
+  int32_t nan_guard;  /* latch on a non-finite change norm (quirk Q6)                  */
+  int32_t stage_pressure; /* 0: SG (quirk Q1, grad p^n in all stages); 1: FSG smoother */
+  int32_t rec_cap;    /* capacity of `rec` in records                                  */
+  /* operators, read-only: row-major LD x LD, zero padded                               */
+  const double *Dx, *D2x, *Dy, *D2y;   /* sg.py:188-193                                */
+  const double *IxF, *GxF;  /* Interp_x embedded in full indexing; Dx @ IxF  (sg.py:209, 270-275) */
+  const double *IyF, *GyF;  /* Interp_y embedded;                  Dy @ IyF  (sg.py:210, 270-276) */
+  const double *wx, *wy;    /* quadrature weights, length LD       (sg.py:489-490)     */
+  const double *ulid;       /* lid profile u_lid(x_i), length LD   (corner.py:80-112)  */
+  /* state phi^n and its transposed copies                                              */
+  double *U, *UT, *V, *VT, *P;
+  /* RK stage buffers (sg.py:438-442), ping-pong A/B                                    */
+  double *UA, *UAT, *VA, *VAT, *PA;
+  double *UB, *UBT, *VB, *VBT, *PB;
+  /* pressure path: T1T = (P IyF^T)^T, T2T = (P GyF^T)^T, grad p on the full grid       */
+  double *T1T, *T2T, *PX, *PY;
+  /* diagnostics: vorticity and its transpose                                           */
+  double *W, *WT;
+  /* reductions / control                                                               */
+  double  *partials;  /* (T*T + edge blocks) * LDC_NPART doubles per producing kernel, 4 slabs */
+  int64_t  partials_stride; /* doubles between slabs                                    */
+  double  *scal;      /* LDC_SCAL_LEN doubles                                           */
+  int32_t *ctrl;      /* LDC_CTRL_LEN int32                                             */
+  double  *rec;       /* rec_cap * LDC_REC_LEN doubles, ring indexed by iteration       */
+} ldc_problem;
+
+typedef struct ldc_solver ldc_solver;   /* opaque */
+
+/* library / device -------------------------------------------------------------------- */
+int         ldc_version(void);
+const char *ldc_error_string(int code);
+/* fills arch[] with the gcnArchName of the current device; 0 if it is gfx950            */
+int         ldc_device_check(char *arch, int arch_len);
+
+/* solver handle ------------------------------------------------------------------------ */
+/* validates the description and copies it; no device work                               */
+int ldc_solver_create(const ldc_problem *desc, ldc_solver **out);
+int ldc_solver_destroy(ldc_solver *s);
+
+/* one RK stage (k = 0..3) of SGSolver.step: residual + update + BCs fused               */
+/* replaces sg.py:434-447 (_compute_residuals :278-346, axpy :438-446, BCs :348-385)     */
+int ldc_stage(ldc_solver *s, int k, void *stream);
+/* T1T/T2T from the current pressure (first half of _interpolate_pressure_gradient,     */
+/* sg.py:270); `which` 0: P, 1: PA, 2: PB                                                */
+int ldc_pressure_transform(ldc_solver *s, int which, void *stream);
+/* vorticity, enstrophy and palinstrophy partial sums of the current state               */
+/* replaces sg.py:510-550 (called per iteration at base.py:274-276)                      */
+int ldc_diagnostics(ldc_solver *s, void *stream);
+/* reduces the partial sums: change norms, residual norms, E/Z/P, next dt, latch, record */
+/* replaces sg.py:387-408, base.py:250-258, :283-286, sg.py:463-473                      */
+int ldc_finalize(ldc_solver *s, int with_diagnostics, void *stream);
+/* computes dt for the first iteration from the current state (sg.py:387-408)            */
+int ldc_prime(ldc_solver *s, void *stream);
+
+/* n_iters iterations of base.py:243-313 enqueued on `stream` (hipGraph replay where     */
+/* possible); with_diagnostics=0 gives the step()-only loop.  Does not synchronise.      */
+int ldc_solver_enqueue(ldc_solver *s, int n_iters, int with_diagnostics, void *stream);
+/* iterations captured per graph (default 32); must be set before the first enqueue      */
+int ldc_solver_set_graph_iters(ldc_solver *s, int iters_per_graph);
+
+/* debugging aid for parity tests: one residual evaluation of state `which`              */
+/* (0: U/V, 1: UA/VA, 2: UB/VB) with every intermediate written to LD x LD arrays:       */
+/* out[0..9] = du_dx, du_dy, dv_dx, dv_dy, lap_u, lap_v, dp_dx, dp_dy, R_u, R_v; out[10] = R_p */
+int ldc_residual_debug(ldc_solver *s, int which, double *const out[11], void *stream);
+
+/* generic fp64 MFMA product used by the stream-function solve -------------------------- */
+/* C[i][j] = sum_{k<K16} A[i][k] * B[j][k]  (i,j < R16; all LD-strided, zero padded);     */
+/* scale_mode 0: none; 1: C /= (lam_r[i] + lam_c[j]); transpose_out: store C^T            */
+int ldc_gemm_nt(const double *A, const double *B, double *C, int R16, int K16, int LD,
+                int transpose_out, int scale_mode, const double *lam_r, const double *lam_c,
+                void *stream);
+/* psi from A Psi + Psi B^T = F by fast diagonalisation (replaces the sparse LU of        */
+/* sg.py:556-619): F, work, out are LD x LD padded interior-indexed arrays               */
+int ldc_poisson_fastdiag(const double *Qx, const double *Qxinv, const double *Qy,
+                         const double *Qyinv, const double *lamx, const double *lamy,
+                         const double *F, double *work0, double *work1, double *Psi,
+                         int Mi, int LD, void *stream);
+/* argmin psi, argmax |omega| and the three corner maxima (sg.py:621-709).               */
+/* out_val[5], out_idx[5] (flat index ix*LD+iy): 0 primary, 1 |omega| max, 2 BR, 3 BL, 4 TL */
+int ldc_vortex_extrema(const double *Psi, const double *W, const double *x, const double *y,
+                       int M, int LD, double *out_val, int32_t *out_idx, void *stream);
+
+/* hardware self-test: D = A(16x4) * B(4x16) with the f64 MFMA; used by tests to pin the  */
+/* operand / result lane maps                                                             */
+int ldc_mfma_selftest(const double *A, const double *B, double *D, void *stream);
+/* fp64 MFMA issue-rate micro-benchmark: runs `iters` x 8 independent MFMAs per wave on    */
+/* every SIMD; returns nothing (time it with events); flops = grid*4*iters*8*2048          */
+int ldc_mfma_peak(double *sink, int iters, int grid, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDC_HIP_H */

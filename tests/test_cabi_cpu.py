@@ -1,0 +1,77 @@
+"""CPU-only checks of the boundary: the C-ABI library loads and exports every symbol the
+header declares, argument validation works without a device, and the plugin class refuses
+to run without a GPU (no silent fallback)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from solvers.spectral import ldc_lib
+    return ldc_lib
+
+
+def test_header_and_exports_agree(lib):
+    hdr = (ROOT / "include" / "ldc_hip.h").read_text()
+    declared = set(re.findall(r"\b(ldc_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(lib.EXPORTS)
+    L = lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.ldc_version() == 1
+
+
+def test_struct_size_matches_header(lib):
+    # 4 int32 + 7 double + 4 int32 + 33 ptr + int64 + 3 ptr
+    assert C.sizeof(lib.Problem) == 16 + 56 + 16 + 33 * 8 + 8 + 24
+
+
+def test_argument_validation_needs_no_device(lib):
+    L = lib.lib()
+    h = C.c_void_p()
+    pr = lib.Problem()
+    assert L.ldc_solver_create(C.byref(pr), C.byref(h)) == -1          # LDC_E_ARG
+    assert L.ldc_solver_create(None, C.byref(h)) == -1
+    assert L.ldc_stage(None, 0, None) == -2                             # LDC_E_STATE
+    assert L.ldc_solver_enqueue(None, 1, 1, None) == -2
+    assert L.ldc_gemm_nt(None, None, None, 1, 1, 16, 0, 0, None, None, None) == -1
+    assert b"invalid argument" in L.ldc_error_string(-1)
+
+
+def test_geometry_rules(lib):
+    """T = ceil((M-1)/16); tail iff 16T == M-1; LD multiple of 16 and >= 16T+16."""
+    L = lib.lib()
+    pr = lib.Problem()
+    pr.M, pr.T, pr.tail, pr.LD, pr.rec_cap = 257, 16, 1, 272, 8
+    h = C.c_void_p()
+    # geometry is consistent but pointers are null -> still E_ARG, never a crash
+    assert L.ldc_solver_create(C.byref(pr), C.byref(h)) == -1
+    pr.T = 17
+    assert L.ldc_solver_create(C.byref(pr), C.byref(h)) == -1
+
+
+def test_plugin_refuses_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from solvers.spectral.sg import SGSolver
+    with pytest.raises(lib.LdcError, match="no CPU fallback"):
+        SGSolver(name="spectral", Re=100.0, nx=16, ny=16, basis_type="chebyshev", CFL=1.5)
+
+
+def test_constructor_errors_match_reference():
+    from solvers.spectral.sg import SGSolver
+    with pytest.raises(TypeError):
+        SGSolver(name="spectral", Re=100.0, nx=16, ny=16, bogus_key=1)
+    with pytest.raises(ValueError, match="Unknown basis_type"):
+        SGSolver(name="spectral", Re=100.0, nx=16, ny=16, basis_type="fourier")
+    with pytest.raises(ValueError, match="Unknown corner treatment"):
+        SGSolver(name="spectral", Re=100.0, nx=16, ny=16, basis_type="chebyshev",
+                 corner_treatment="subtraction")

@@ -1,0 +1,188 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against (a) golden vectors
+from the reference and (b) the CPU oracle on identical inputs.
+
+Tolerances (fp64): state after K steps <= 1e-12 abs (the measured noise floor
+between two OpenBLAS kernels on the reference itself is 8e-16); scalars (dt, norms, E/Z/P)
+<= 1e-10 rel; single residual evaluation <= 1e-11 rel to the field maximum.
+"""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import ldc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def make(N, Re, **kw):
+    from solvers.spectral.sg import SGSolver
+    args = dict(name="spectral", Re=float(Re), lid_velocity=1.0, Lx=1.0, Ly=1.0, nx=N, ny=N,
+                tolerance=1e-6, max_iterations=10_000_000, basis_type="chebyshev", CFL=1.5,
+                beta_squared=5.0, corner_treatment="smoothing", corner_smoothing=0.15,
+                multigrid="none", check_every=512, graph_iters=16)
+    args.update(kw)
+    return SGSolver(**args)
+
+
+def rel(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def test_mfma_lane_maps():
+    """Exact-integer A (16x4) and asymmetric B (4x16): D must equal A @ B element for element."""
+    import torch
+    from solvers.spectral import ldc_lib as L
+    L.require_device()
+    rng = np.random.default_rng(0)
+    A = rng.integers(-8, 9, size=(16, 4)).astype(float)
+    B = (np.arange(64).reshape(4, 16) % 7 - 3.0) + 10.0 * np.arange(4)[:, None]
+    dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    dD = torch.zeros((16, 16), dtype=torch.float64, device="cuda")
+    L.check(L.lib().ldc_mfma_selftest(dA.data_ptr(), dB.data_ptr(), dD.data_ptr(), L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(dD.cpu().numpy(), A @ B)
+
+
+@pytest.mark.parametrize("N", [16, 24])
+def test_single_residual_vs_reference(golden_dir, N):
+    g = np.load(golden_dir / "g3_single_stage.npz")
+    s = make(N, 400.0)
+    s.set_state(u=g[f"N{N}_u"], v=g[f"N{N}_v"], p=g[f"N{N}_p"])
+    got = s.residual_fields()
+    for key in ("du_dx", "du_dy", "dv_dx", "dv_dy", "lap_u", "lap_v", "dp_dx", "dp_dy", "R_u", "R_v", "R_p"):
+        assert rel(got[key], g[f"N{N}_{key}"]) < 1e-11, key
+
+
+@pytest.mark.parametrize("N", [20, 32, 47, 64, 80])
+def test_single_residual_vs_oracle(N):
+    """Tail (N multiple of 16) and non-tail sizes, random smooth state, every intermediate."""
+    rng = np.random.default_rng(N)
+    o = orc.OracleSG(N, 250.0)
+    M = N + 1
+    X, Y = np.meshgrid(o.ax.x, o.ay.x, indexing="ij")
+    f = lambda: sum(rng.standard_normal() * np.sin((a + 1) * X + b * Y) for a in range(3) for b in range(3))
+    o.u, o.v, o.p = f(), f(), f()[1:-1, 1:-1].copy()
+    Ru, Rv, Rp, parts = o.residual(o.u, o.v, o.p, want_parts=True)
+    s = make(N, 250.0)
+    s.set_state(u=o.u, v=o.v, p=o.p)
+    got = s.residual_fields()
+    for key, val in parts.items():
+        assert rel(got[key], val.ravel()) < 1e-11, key
+    assert rel(got["R_u"], Ru.ravel()) < 1e-11
+    assert rel(got["R_v"], Rv.ravel()) < 1e-11
+    assert rel(got["R_p"], Rp.ravel()) < 1e-11
+
+
+TRAJ = [(16, 100, 50), (32, 100, 500), (64, 400, 1000), (64, 1000, 3000)]
+
+
+@pytest.mark.parametrize("N,Re,K", TRAJ)
+def test_trajectory_vs_reference(golden_dir, N, Re, K):
+    g = np.load(golden_dir / f"g4_traj_N{N}_Re{Re}_K{K}.npz")
+    s = make(N, Re)
+    rec = s.run_iterations(K)
+    assert rec.shape == (K, 8)
+    assert np.max(np.abs(s.arrays.u - g["u"])) < 1e-12
+    assert np.max(np.abs(s.arrays.v - g["v"])) < 1e-12
+    assert np.max(np.abs(s.arrays.p - g["p"])) < 1e-12
+    assert rel(rec[:, 7], g["dt"]) < 1e-12
+    assert np.max(np.abs(rec[:, 0] - g["rel"]) / (np.abs(g["rel"]) + 1e-9)) < 1e-8
+    assert rel(rec[:, 1:4], g["res"]) < 1e-10
+    assert rel(rec[:, 4], g["E"]) < 1e-10
+    assert rel(rec[:, 5], g["Z"]) < 1e-10
+    assert rel(rec[:, 6], g["P"]) < 1e-10
+    # vorticity, stream function (reference: sparse LU) and the vortex table
+    assert rel(s._compute_vorticity(), g["omega"]) < 1e-10
+    psi, _, _ = s._compute_streamfunction()
+    assert np.max(np.abs(psi - g["psi"])) < 1e-10 * np.max(np.abs(g["psi"]))
+    vm = s.compute_vortex_metrics()
+    for key, ref in zip(g["vortex_keys"], g["vortex_vals"]):
+        assert abs(vm[str(key)] - ref) <= 1e-9 * max(abs(ref), 1.0), key
+
+
+def test_variants_vs_reference(golden_dir):
+    g = np.load(golden_dir / "g4b_variants.npz")
+    meta = json.loads((golden_dir / "g4b_variants.json").read_text())
+    for name, c in meta.items():
+        s = make(c["N"], c["Re"], **c["kw"])
+        rec = s.run_iterations(c["K"])
+        assert np.max(np.abs(s.arrays.u - g[f"{name}_u"])) < 1e-12, name
+        assert np.max(np.abs(s.arrays.v - g[f"{name}_v"])) < 1e-12, name
+        assert np.max(np.abs(s.arrays.p - g[f"{name}_p"])) < 1e-12, name
+        assert rel(rec[:, 7], g[f"{name}_dt"]) < 1e-12, name
+        assert rel(rec[:, 6], g[f"{name}_P"]) < 1e-9, name
+
+
+def test_graph_replay_equals_eager_launches():
+    """hipGraph replays and plain launches must give bit-identical trajectories."""
+    a = make(32, 100.0, graph_iters=8, check_every=64)
+    b = make(32, 100.0, graph_iters=4096, check_every=64)     # never reaches a full graph: eager
+    ra, rb = a.run_iterations(64), b.run_iterations(64)
+    assert np.array_equal(ra, rb)
+    assert np.array_equal(a.arrays.u, b.arrays.u) and np.array_equal(a.arrays.p, b.arrays.p)
+
+
+def test_runs_are_deterministic():
+    a, b = make(64, 400.0), make(64, 400.0)
+    ra, rb = a.run_iterations(200), b.run_iterations(200)
+    assert np.array_equal(ra, rb) and np.array_equal(a.arrays.v, b.arrays.v)
+
+
+def test_step_only_loop_matches_full_loop():
+    """diagnostics=False (the step()-only rate) must not change the trajectory."""
+    a, b = make(32, 100.0), make(32, 100.0)
+    ra = a.run_iterations(100, diagnostics=True)
+    rb = b.run_iterations(100, diagnostics=False)
+    assert np.array_equal(a.arrays.u, b.arrays.u)
+    assert np.array_equal(ra[:, :5], rb[:, :5]) and not rb[:, 5:7].any()
+
+
+def test_n256_short_run_vs_oracle():
+    """BASELINE config 3 geometry (N=256, Re=1000): 25 iterations against the oracle."""
+    N, Re, K = 256, 1000.0, 25
+    o = orc.OracleSG(N, Re)
+    dts, Es, Ps = [], [], []
+    for _ in range(K):
+        dts.append(o.step()); Es.append(o.energy()); Ps.append(o.palinstrophy())
+    s = make(N, Re)
+    rec = s.run_iterations(K)
+    M = N + 1
+    assert np.max(np.abs(s.arrays.u.reshape(M, M) - o.u)) < 1e-12
+    assert np.max(np.abs(s.arrays.v.reshape(M, M) - o.v)) < 1e-12
+    assert np.max(np.abs(s.arrays.p.reshape(M - 2, M - 2) - o.p)) < 1e-12
+    assert rel(rec[:, 7], np.array(dts)) < 1e-12
+    assert rel(rec[:, 4], np.array(Es)) < 1e-10
+    assert rel(rec[:, 6], np.array(Ps)) < 1e-9
+
+
+def test_solve_converges_like_reference(golden_dir):
+    """Full solve() at N=32, Re=100, tol 1e-6: the reference stops after 59 649 iterations."""
+    meta = json.loads((golden_dir / "g7_converged_N32_Re100.json").read_text())["metrics"]
+    g = np.load(golden_dir / "g7_converged_N32_Re100.npz")
+    s = make(32, 100.0, check_every=2048, graph_iters=32)
+    s.solve()
+    m = s.metrics
+    assert m.converged and abs(m.iterations - meta["iterations"]) <= 2
+    if m.iterations == meta["iterations"]:
+        assert np.max(np.abs(s.fields.u - g["u"])) < 1e-11
+        assert np.max(np.abs(s.fields.p - g["p"])) < 1e-10
+        assert abs(m.final_residual - meta["final_residual"]) < 1e-9 * meta["final_residual"] + 1e-15
+    for key in ("final_energy", "final_enstrophy", "final_palinstrophy", "psi_min", "psi_min_x", "psi_min_y",
+                "omega_center", "omega_max", "psi_BR", "psi_BL", "u_momentum_residual", "continuity_residual"):
+        assert getattr(m, key) == pytest.approx(meta[key], rel=1e-7, abs=1e-10), key
+    assert len(s.time_series.rel_iter_residual) == 1000
+    # a second solve() on the converged state stops right after the warm-up
+    s.solve(max_iter=50)
+    assert s.metrics.iterations <= 12
+
+
+def test_max_iterations_and_nan_guard():
+    s = make(32, 100.0)
+    s.solve(max_iter=37)
+    assert s.metrics.iterations == 37 and not s.metrics.converged
+    assert len(s.time_series.rel_iter_residual) == 27
+    # N=32, Re=1000 blows up with the default CFL; nan_guard exits early
+    d = make(32, 1000.0, nan_guard=True, check_every=512)
+    d.solve(max_iter=4000)
+    assert not d.metrics.converged and d.metrics.iterations < 4000
