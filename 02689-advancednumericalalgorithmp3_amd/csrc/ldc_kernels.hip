@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void stage_kernel(const StageArgs a) {
     if (e < 2 * M - 1) {
       const int i = (e < M) ? m1 : (e - M);
       const int j = (e < M) ? e : m1;
-      const NodeDerivs d = edge_node(a, i, j, lane, GP || DUMP);
+      const NodeDerivs d = edge_node(a, i, j, lane, true);   // PX/PY hold tile nodes only
       const size_t ij = (size_t)i * LD + j;
       const double u = a.Uin[ij], v = a.Vin[ij];
       const double Ru = -(u * d.ux + v * d.uy) - d.px + a.nu * d.lu;
