@@ -134,213 +134,522 @@ struct StageArgs {
   double *PX, *PY;                        // grad p: written when GP, read otherwise
   double *Uout, *UoutT, *Vout, *VoutT, *Pout;
   const double *ulid, *wx, *wy;
+  const double *DxL, *D2xL, *DyL, *D2yL;   // last columns (index M-1) of the four operators
   const double* scal;
-  const int* ctrl;
+  int* ctrl;
   double* partials;
+  int ablate;                             // timing experiments only: 1 skip MFMAs, 2 skip operand loads
   double* dump[11];
 };
-
-struct NodeDerivs {
-  double ux, vx, uy, vy, lu, lv, px, py;
-};
-
-// Everything the residual needs at ONE node, by full-length dot products (edge nodes of
-// the `tail` case: index M-1 is outside the MFMA tiles).  Wave-cooperative.
-__device__ __forceinline__ NodeDerivs edge_node(const StageArgs& a, int i, int j, int lane, bool gp) {
-  const int n = a.M, ld = a.LD;
-  const double *dxi = a.Dx + (size_t)i * ld, *d2xi = a.D2x + (size_t)i * ld;
-  const double *dyj = a.Dy + (size_t)j * ld, *d2yj = a.D2y + (size_t)j * ld;
-  const double *ui = a.Uin + (size_t)i * ld, *vi = a.Vin + (size_t)i * ld;
-  const double *utj = a.UinT + (size_t)j * ld, *vtj = a.VinT + (size_t)j * ld;
-  NodeDerivs d;
-  d.ux = dot_rows(dxi, utj, n, lane);
-  d.vx = dot_rows(dxi, vtj, n, lane);
-  d.uy = dot_rows(ui, dyj, n, lane);
-  d.vy = dot_rows(vi, dyj, n, lane);
-  d.lu = dot_rows(d2xi, utj, n, lane) + dot_rows(ui, d2yj, n, lane);
-  d.lv = dot_rows(d2xi, vtj, n, lane) + dot_rows(vi, d2yj, n, lane);
-  if (gp) {
-    d.px = dot_rows(a.GxF + (size_t)i * ld, a.T1T + (size_t)j * ld, n, lane);
-    d.py = dot_rows(a.IxF + (size_t)i * ld, a.T2T + (size_t)j * ld, n, lane);
-  } else {
-    d.px = a.PX[(size_t)i * ld + j];
-    d.py = a.PY[(size_t)i * ld + j];
-  }
-  return d;
-}
 
 // slots of the stage-4 partial sums
 enum { PS_DU2 = 0, PS_DV2, PS_U02, PS_V02, PS_RU2, PS_RV2, PS_RP2, PS_E, PS_NSUM, PS_UMAX = PS_NSUM, PS_VMAX, PS_N };
 static_assert(PS_N <= LDC_NPART, "partials row too small");
+static_assert(PS_NSUM == 8, "stage-4 reduction assigns one wave per sum");
 
-// GP   : also contract the pressure transforms (px, py) and store them
-// LAST : stage 4 -- pressure update, in-place state, reductions, edge-node residuals
-// DUMP : parity-test mode, writes every intermediate, touches no state
-template <bool GP, bool LAST, bool DUMP>
-__global__ __launch_bounds__(kThreads) void stage_kernel(const StageArgs a) {
-  constexpr int NA = GP ? 8 : 6;
-  __shared__ __attribute__((aligned(16))) double red[kWaves * NA * 4 * 64];
+constexpr int kStageWaves = 8;                 // 2 waves per SIMD: needed to saturate the f64 MFMA pipe
+constexpr int kStageThreads = 64 * kStageWaves;
 
-  if (!DUMP && a.ctrl[LDC_CTRL_DONE] != 0) return;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int M = a.M, LD = a.LD, T = a.T;
-  const int nt = T * T;
-  const double dt = a.scal[LDC_SCAL_DT];
-  const double adt = a.alpha * dt;
+__device__ __forceinline__ double dot4(const v4d& x, const v4d& y) {
+  return (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]);
+}
+// sum over the four k-quads of a wave: lanes l, l^16, l^32, l^48 hold the same (row|col) index
+__device__ __forceinline__ double quad_sum(double x) {
+  x += __shfl_xor(x, 16);
+  x += __shfl_xor(x, 32);
+  return x;
+}
 
-  if ((int)blockIdx.x >= nt) {
-    // ---- edge nodes (tail case; only launched for LAST or DUMP) -----------------------
-    const int e = ((int)blockIdx.x - nt) * kWaves + wv;   // one wave per node
-    const int m1 = M - 1;
-    double sums[PS_NSUM] = {0, 0, 0, 0, 0, 0, 0, 0};
-    double maxs[2] = {0, 0};
-    if (e < 2 * M - 1) {
-      const int i = (e < M) ? m1 : (e - M);
-      const int j = (e < M) ? e : m1;
-      const NodeDerivs d = edge_node(a, i, j, lane, true);   // PX/PY hold tile nodes only
-      const size_t ij = (size_t)i * LD + j;
-      const double u = a.Uin[ij], v = a.Vin[ij];
-      const double Ru = -(u * d.ux + v * d.uy) - d.px + a.nu * d.lu;
-      const double Rv = -(u * d.vx + v * d.vy) - d.py + a.nu * d.lv;
-      if (DUMP) {
-        if (lane == 0) {
-          a.dump[0][ij] = d.ux; a.dump[1][ij] = d.uy; a.dump[2][ij] = d.vx; a.dump[3][ij] = d.vy;
-          a.dump[4][ij] = d.lu; a.dump[5][ij] = d.lv; a.dump[6][ij] = d.px; a.dump[7][ij] = d.py;
-          a.dump[8][ij] = Ru;   a.dump[9][ij] = Rv;
-        }
-      } else if (lane == 0) {
-        const double u0 = a.U0[ij], v0 = a.V0[ij];   // boundary values never change
-        sums[PS_U02] = u0 * u0; sums[PS_V02] = v0 * v0;
-        sums[PS_RU2] = Ru * Ru; sums[PS_RV2] = Rv * Rv;
-        sums[PS_E] = a.wx[i] * a.wy[j] * (u0 * u0 + v0 * v0);
-        maxs[0] = fabs(u0); maxs[1] = fabs(v0);
-      }
-    }
-    if (!DUMP) block_reduce_store<PS_NSUM, 2>(sums, maxs, red, a.partials + (size_t)blockIdx.x * LDC_NPART, lane, wv);
+// One wave's operands.  Both roles contract the full 2x2 combination {A0,A1} x {B0,B1}:
+//   role 0 (x-derivatives): A0 = Dx, A1 = D2x (rows I)   B0 = UT, B1 = VT (rows J)   A2 = GxF, B2 = T1T
+//        c00 = du/dx   c01 = dv/dx   c10 = d2u/dx2   c11 = d2v/dx2   c4 = dp/dx
+//   role 1 (y-derivatives): A0 = U,  A1 = V   (rows I)   B0 = Dy, B1 = D2y (rows J)  A2 = IxF, B2 = T2T
+//        c00 = du/dy   c10 = dv/dy   c01 = d2u/dy2   c11 = d2v/dy2   c4 = dp/dy
+struct RoleOps {
+  const double *A0, *A1, *B0, *B1, *A2, *B2;
+  int ablate;
+};
+
+template <bool GP>
+struct RoleFrags {
+  v4d a0, a1, b0, b1, a2, b2;
+};
+
+template <bool GP>
+__device__ __forceinline__ void load_role(RoleFrags<GP>& f, const RoleOps& o, int LD, int r0, int c0, int k0, int lane) {
+  if (o.ablate & 2) {
+    const double x = 1e-3 * lane + k0;
+    f.a0 = (v4d){x, x, x, x}; f.a1 = f.a0; f.b0 = f.a0; f.b1 = f.a0; f.a2 = f.a0; f.b2 = f.a0;
     return;
   }
+  f.a0 = ldfrag(o.A0, LD, r0, k0, lane); f.a1 = ldfrag(o.A1, LD, r0, k0, lane);
+  f.b0 = ldfrag(o.B0, LD, c0, k0, lane); f.b1 = ldfrag(o.B1, LD, c0, k0, lane);
+  if (GP) { f.a2 = ldfrag(o.A2, LD, r0, k0, lane); f.b2 = ldfrag(o.B2, LD, c0, k0, lane); }
+}
+
+template <bool GP, int NA>
+__device__ __forceinline__ void mfma_role(const RoleFrags<GP>& f, v4d (&acc)[NA], int ablate) {
+  if (ablate & 1) {   // keep the operands live without issuing MFMAs
+    acc[0][0] += f.a0[0] + f.b0[1] + f.a1[2] + f.b1[3];
+    if (GP) acc[4][0] += f.a2[0] + f.b2[0];
+    return;
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    acc[0] = MFMA_F64(f.a0[s], f.b0[s], acc[0]);
+    acc[1] = MFMA_F64(f.a0[s], f.b1[s], acc[1]);
+    acc[2] = MFMA_F64(f.a1[s], f.b0[s], acc[2]);
+    acc[3] = MFMA_F64(f.a1[s], f.b1[s], acc[3]);
+    if (GP) acc[4] = MFMA_F64(f.a2[s], f.b2[s], acc[4]);
+  }
+}
+
+// Index M-1 lies outside the MFMA tiles when 16*T == M-1 (`tail`).  The residual at those
+// nodes feeds only ||R_u||, ||R_v|| (quirk Q4: boundary nodes count) but must be exact.
+// Tiles of the last tile row / column get it almost for free: the row (column) vector of
+// index M-1 dotted with fragments that are already in registers, on the otherwise idle VALU.
+//   er[ai][bj] : row node  (M-1, c0+idx) = A_i[M-1, k] . B_j[c0+idx, k]
+//   ec[ai][bj] : col node  (r0+idx, M-1) = A_i[r0+idx, k] . B_j[M-1, k]
+//   ek[ai][bj] : corner    (M-1, M-1)
+struct EdgeAcc {
+  double er[5], ec[5], ek[5];
+};
+
+// VEL: the four velocity contractions (needed where R_u, R_v are formed: LAST, DUMP)
+// GP : the pressure-gradient contraction (stage 1 stores it for the later stages)
+template <bool VEL, bool GP>
+__device__ __forceinline__ void edge_group(EdgeAcc& e, const RoleFrags<GP>& f, const RoleOps& o, int LD, int m1,
+                                           int k0, int lane, bool rowE, bool colE) {
+  const size_t off = (size_t)m1 * LD + k0 + 4 * (lane >> 4);
+  v4d ar0, ar1, ar2, bc0, bc1, bc2;
+  if (rowE) {
+    if (VEL) {
+      ar0 = *reinterpret_cast<const v4d*>(o.A0 + off);
+      ar1 = *reinterpret_cast<const v4d*>(o.A1 + off);
+      e.er[0] += dot4(ar0, f.b0); e.er[1] += dot4(ar0, f.b1);
+      e.er[2] += dot4(ar1, f.b0); e.er[3] += dot4(ar1, f.b1);
+    }
+    if (GP) { ar2 = *reinterpret_cast<const v4d*>(o.A2 + off); e.er[4] += dot4(ar2, f.b2); }
+  }
+  if (colE) {
+    if (VEL) {
+      bc0 = *reinterpret_cast<const v4d*>(o.B0 + off);
+      bc1 = *reinterpret_cast<const v4d*>(o.B1 + off);
+      e.ec[0] += dot4(f.a0, bc0); e.ec[1] += dot4(f.a0, bc1);
+      e.ec[2] += dot4(f.a1, bc0); e.ec[3] += dot4(f.a1, bc1);
+    }
+    if (GP) { bc2 = *reinterpret_cast<const v4d*>(o.B2 + off); e.ec[4] += dot4(f.a2, bc2); }
+  }
+  if (rowE && colE) {
+    if (VEL) {
+      e.ek[0] += dot4(ar0, bc0); e.ek[1] += dot4(ar0, bc1);
+      e.ek[2] += dot4(ar1, bc0); e.ek[3] += dot4(ar1, bc1);
+    }
+    if (GP) e.ek[4] += dot4(ar2, bc2);
+  }
+}
+
+// block-wide reduction over the 8 stage waves (fixed order => deterministic)
+template <int NV, int NM>
+__device__ __forceinline__ void stage_block_reduce(double (&sums)[NV], double (&maxs)[NM], double* sm, double* dst,
+                                                   int lane, int wv) {
+#pragma unroll
+  for (int v = 0; v < NV; ++v) sums[v] = wave_sum(sums[v]);
+#pragma unroll
+  for (int v = 0; v < NM; ++v) maxs[v] = wave_max(maxs[v]);
+  if (lane == 0) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) sm[wv * (NV + NM) + v] = sums[v];
+#pragma unroll
+    for (int v = 0; v < NM; ++v) sm[wv * (NV + NM) + NV + v] = maxs[v];
+  }
+  __syncthreads();
+  const int t = wv * 64 + lane;
+  if (t < NV + NM) {
+    double r = sm[t];
+#pragma unroll
+    for (int w = 1; w < kStageWaves; ++w) {
+      const double x = sm[w * (NV + NM) + t];
+      r = (t < NV) ? (r + x) : fmax(r, x);
+    }
+    dst[t] = r;
+  }
+}
+
+// dynamic LDS carve (doubles): [0, RED) per-wave accumulators; then edge partials, two
+// transposition tiles and the block-reduction scratch
+template <bool GP>
+struct StageLds {
+  static constexpr int NA = GP ? 5 : 4;
+  static constexpr int RED = kStageWaves * NA * 4 * 64;
+  static constexpr int EDGE = RED;                         // [wave][15][16]
+  static constexpr int TILE = EDGE + kStageWaves * 15 * 16;  // 2 x 16 x 17
+  static constexpr int SCR = TILE + 2 * 16 * 17;           // kStageWaves * PS_N
+  static constexpr int TOTAL = SCR + kStageWaves * PS_N;
+  static constexpr size_t BYTES = sizeof(double) * TOTAL;
+};
+
+// GP   : also contract the pressure transforms (px, py) and store them
+// LAST : stage 4 -- pressure update, in-place state, reductions (incl. the index-M-1 nodes)
+// DUMP : parity-test mode, writes every intermediate, touches no state
+template <bool GP, bool LAST, bool DUMP>
+__global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs a) {
+  using L = StageLds<GP>;
+  constexpr int NA = L::NA;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* red = lds;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int role = wv >> 2, kq = wv & 3;
+  const int M = a.M, LD = a.LD, T = a.T, m1 = M - 1;
 
   int I, J;
   tile_of_block((int)blockIdx.x, T, I, J);
   const int r0 = 16 * I, c0 = 16 * J;
+  constexpr bool VEL = LAST || DUMP;          // nodes of index M-1 need R_u, R_v here
+  constexpr bool EDGES = GP || VEL;
+  const bool rowE = EDGES && a.tail && (I == T - 1);
+  const bool colE = EDGES && a.tail && (J == T - 1);
 
-  // ---- contraction over k, split over the four waves ----------------------------------
+  RoleOps o;
+  o.ablate = a.ablate;
+  if (role == 0) { o.A0 = a.Dx; o.A1 = a.D2x; o.B0 = a.UinT; o.B1 = a.VinT; o.A2 = a.GxF; o.B2 = a.T1T; }
+  else           { o.A0 = a.Uin; o.A1 = a.Vin; o.B0 = a.Dy; o.B1 = a.D2y; o.A2 = a.IxF; o.B2 = a.T2T; }
+
+  // ---- first fragments in flight before anything else ------------------------------------
+  int g = kq;
+  RoleFrags<GP> fa, fb;
+  load_role<GP>(fa, o, LD, r0, c0, 16 * (g < T ? g : 0), lane);
+
+  // the latch and dt are read only now, behind the first operand loads (reads are harmless)
+  if (!DUMP && a.ctrl[LDC_CTRL_DONE] != 0) return;
+  const int step0 = a.ctrl[LDC_CTRL_STEP];
+  const double adt = a.alpha * a.scal[LDC_SCAL_DT];
+
+  // ---- pointwise operands of the epilogue (threads 0..255 own one node each) -----------------
+  const int ti = 4 * (wv & 3) + (lane >> 4), tj = lane & 15;
+  const int i = r0 + ti, j = c0 + tj;
+  const size_t ij = (size_t)i * LD + j;
+  const bool owner = tid < 256;
+  double uin = 0, vin = 0, u0 = 0, v0 = 0, p0 = 0, px = 0, py = 0;
+  double dxl = 0, d2xl = 0, dyl = 0, d2yl = 0, ue = 0, ve = 0, un_ = 0, vn_ = 0, lidv = 0, wq = 0;
+  if (owner) {
+    uin = a.Uin[ij]; vin = a.Vin[ij];
+    if (!DUMP) { u0 = a.U0[ij]; v0 = a.V0[ij]; }
+    if (!DUMP && a.Pout != nullptr) p0 = a.P0[ij];
+    if (!GP) { px = a.PX[ij]; py = a.PY[ij]; }
+    if (a.tail) {
+      dxl = a.DxL[i]; d2xl = a.D2xL[i]; dyl = a.DyL[j]; d2yl = a.D2yL[j];
+      ue = a.Uin[(size_t)m1 * LD + j]; ve = a.Vin[(size_t)m1 * LD + j];    // east-wall row
+      un_ = a.Uin[(size_t)i * LD + m1]; vn_ = a.Vin[(size_t)i * LD + m1];  // lid column
+    }
+    lidv = a.ulid[i];
+    if (LAST) wq = a.wx[i] * a.wy[j];
+  }
+
+  // ---- contraction over k: this wave's quarter, loads one group ahead (A/B ping-pong) --------
   v4d acc[NA];
 #pragma unroll
   for (int q = 0; q < NA; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
-  // acc: 0 ux, 1 vx, 2 uy, 3 vy, 4 lap u, 5 lap v, (6 px, 7 py)
-  for (int g = wv; g < T; g += kWaves) {
-    const int k0 = 16 * g;
-    const v4d fDx = ldfrag(a.Dx, LD, r0, k0, lane), fD2x = ldfrag(a.D2x, LD, r0, k0, lane);
-    const v4d fUT = ldfrag(a.UinT, LD, c0, k0, lane), fVT = ldfrag(a.VinT, LD, c0, k0, lane);
-    const v4d fU = ldfrag(a.Uin, LD, r0, k0, lane), fV = ldfrag(a.Vin, LD, r0, k0, lane);
-    const v4d fDy = ldfrag(a.Dy, LD, c0, k0, lane), fD2y = ldfrag(a.D2y, LD, c0, k0, lane);
-    v4d fGx, fIx, fT1, fT2;
-    if (GP) {
-      fGx = ldfrag(a.GxF, LD, r0, k0, lane); fIx = ldfrag(a.IxF, LD, r0, k0, lane);
-      fT1 = ldfrag(a.T1T, LD, c0, k0, lane); fT2 = ldfrag(a.T2T, LD, c0, k0, lane);
-    }
+  EdgeAcc ea;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      acc[0] = MFMA_F64(fDx[s], fUT[s], acc[0]);
-      acc[1] = MFMA_F64(fDx[s], fVT[s], acc[1]);
-      acc[2] = MFMA_F64(fU[s], fDy[s], acc[2]);
-      acc[3] = MFMA_F64(fV[s], fDy[s], acc[3]);
-      acc[4] = MFMA_F64(fD2x[s], fUT[s], acc[4]);
-      acc[5] = MFMA_F64(fD2x[s], fVT[s], acc[5]);
-      if (GP) {
-        acc[6] = MFMA_F64(fGx[s], fT1[s], acc[6]);
-        acc[7] = MFMA_F64(fIx[s], fT2[s], acc[7]);
+  for (int q = 0; q < 5; ++q) { ea.er[q] = 0.0; ea.ec[q] = 0.0; ea.ek[q] = 0.0; }
+  for (; g < T; g += 2 * 4) {
+    const int g1 = g + 4, g2 = g + 8;
+    load_role<GP>(fb, o, LD, r0, c0, 16 * (g1 < T ? g1 : g), lane);   // clamped: harmless reload
+    mfma_role<GP, NA>(fa, acc, a.ablate);
+    if (rowE || colE) edge_group<VEL, GP>(ea, fa, o, LD, m1, 16 * g, lane, rowE, colE);
+    if (g1 < T) {
+      load_role<GP>(fa, o, LD, r0, c0, 16 * (g2 < T ? g2 : g1), lane);
+      mfma_role<GP, NA>(fb, acc, a.ablate);
+      if (rowE || colE) edge_group<VEL, GP>(ea, fb, o, LD, m1, 16 * g1, lane, rowE, colE);
+    }
+  }
+
+  // ---- all partial results to LDS ---------------------------------------------------------------
+#pragma unroll
+  for (int q = 0; q < NA; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((wv * NA + q) * 4 + r) * 64 + lane] = acc[q][r];
+  if (rowE || colE) {
+    double* er = lds + L::EDGE + wv * 15 * 16;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      if ((q < 4 && !VEL) || (q == 4 && !GP)) continue;
+      const double x = quad_sum(ea.er[q]), y = quad_sum(ea.ec[q]), z = quad_sum(ea.ek[q]);
+      if (lane < 16) { er[q * 16 + lane] = x; er[(5 + q) * 16 + lane] = y; er[(10 + q) * 16 + lane] = z; }
+    }
+  }
+  __syncthreads();
+
+  // sum of one accumulator over the four K-quarters of a role, at this thread's node
+  auto rsum = [&](int rl, int q) {
+    const int w = wv & 3;
+    double x = red[(((rl * 4 + 0) * NA + q) * 4 + w) * 64 + lane];
+    x += red[(((rl * 4 + 1) * NA + q) * 4 + w) * 64 + lane];
+    x += red[(((rl * 4 + 2) * NA + q) * 4 + w) * 64 + lane];
+    x += red[(((rl * 4 + 3) * NA + q) * 4 + w) * 64 + lane];
+    return x;
+  };
+  // same for an edge value: kind 0 row node, 1 column node, 2 corner; idx = position in the tile
+  auto esum = [&](int rl, int kind, int q, int idx) {
+    const double* base = lds + L::EDGE + (kind * 5 + q) * 16 + idx;
+    double x = base[(rl * 4 + 0) * 15 * 16];
+    x += base[(rl * 4 + 1) * 15 * 16];
+    x += base[(rl * 4 + 2) * 15 * 16];
+    x += base[(rl * 4 + 3) * 15 * 16];
+    return x;
+  };
+
+  double sums[PS_NSUM] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double maxs[2] = {0, 0};
+  double un = 0.0, vn = 0.0;
+  double* tu = lds + L::TILE;
+  double* tv = tu + 16 * 17;
+
+  if (owner) {
+    // ---- pointwise epilogue: thread owns node (i, j) ---------------------------------------------
+    const bool valid = (i < M) && (j < M);
+    const bool interior = (i >= 1) && (i <= M - 2) && (j >= 1) && (j <= M - 2);
+    double ux = rsum(0, 0), vx = rsum(0, 1), lu = rsum(0, 2), lv = rsum(0, 3);
+    double uy = rsum(1, 0), vy = rsum(1, 2);
+    lu += rsum(1, 1); lv += rsum(1, 3);
+    if (a.tail) {
+      // k = M-1 lies outside the MFMA range: exact rank-1 completion of every contraction
+      ux += dxl * ue; vx += dxl * ve;
+      uy += un_ * dyl; vy += vn_ * dyl;
+      lu += d2xl * ue + un_ * d2yl;
+      lv += d2xl * ve + vn_ * d2yl;
+    }
+    if (GP) {
+      px = valid ? rsum(0, 4) : 0.0;   // row M-1 of T1T/T2T meets a zero column of GxF/IxF: no completion term
+      py = valid ? rsum(1, 4) : 0.0;
+      if (!DUMP) { a.PX[ij] = px; a.PY[ij] = py; }
+    }
+    const double Ru = -(uin * ux + vin * uy) - px + a.nu * lu;
+    const double Rv = -(uin * vx + vin * vy) - py + a.nu * lv;
+    const double Rp = -a.beta2 * (ux + vy);
+    if (DUMP) {
+      if (valid) {
+        a.dump[0][ij] = ux; a.dump[1][ij] = uy; a.dump[2][ij] = vx; a.dump[3][ij] = vy;
+        a.dump[4][ij] = lu; a.dump[5][ij] = lv; a.dump[6][ij] = px; a.dump[7][ij] = py;
+        a.dump[8][ij] = Ru; a.dump[9][ij] = Rv;
+        if (interior) a.dump[10][ij] = Rp;
       }
-      acc[4] = MFMA_F64(fU[s], fD2y[s], acc[4]);
-      acc[5] = MFMA_F64(fV[s], fD2y[s], acc[5]);
+    } else {
+      un = u0 + adt * Ru; vn = v0 + adt * Rv;
+      // walls first, lid last (sg.py:348-385): the lid row wins the two top corners
+      if (!valid) { un = 0.0; vn = 0.0; }
+      else if (j == M - 1) { un = lidv; vn = 0.0; }
+      else if (i == 0 || i == M - 1 || j == 0) { un = 0.0; vn = 0.0; }
+      a.Uout[ij] = un;
+      a.Vout[ij] = vn;
+      if (a.Pout != nullptr) a.Pout[ij] = interior ? (p0 + adt * Rp) : 0.0;
+      tu[ti * 17 + tj] = un;
+      tv[ti * 17 + tj] = vn;
+      if (LAST) {
+        const double du = un - u0, dv = vn - v0;
+        sums[PS_DU2] = valid ? du * du : 0.0;
+        sums[PS_DV2] = valid ? dv * dv : 0.0;
+        sums[PS_U02] = valid ? u0 * u0 : 0.0;
+        sums[PS_V02] = valid ? v0 * v0 : 0.0;
+        sums[PS_RU2] = valid ? Ru * Ru : 0.0;
+        sums[PS_RV2] = valid ? Rv * Rv : 0.0;
+        sums[PS_RP2] = interior ? Rp * Rp : 0.0;
+        sums[PS_E] = valid ? wq * (un * un + vn * vn) : 0.0;
+        maxs[0] = fabs(un);
+        maxs[1] = fabs(vn);
+      }
+    }
+  } else if (rowE || colE) {
+    // ---- nodes of index M-1 handled by this tile: threads 256.. finish them ------------------------
+    const int t = tid - 256;
+    const int kind = t >> 4, idx = t & 15;           // 0: (M-1, c0+idx)   1: (r0+idx, M-1)   2: corner
+    const bool act = (kind == 0 && rowE) || (kind == 1 && colE) || (kind == 2 && idx == 0 && rowE && colE);
+    if (kind < 3 && act) {
+      const int ei = (kind == 1) ? (r0 + idx) : m1;
+      const int ej = (kind == 0) ? (c0 + idx) : m1;
+      const size_t eij = (size_t)ei * LD + ej;
+      // role 0: c00 ux, c01 vx, c10 luX, c11 lvX, c4 px     role 1: c00 uy, c10 vy, c01 luY, c11 lvY, c4 py
+      double epx, epy;
+      if (GP) {
+        epx = esum(0, kind, 4, idx); epy = esum(1, kind, 4, idx);
+        if (!DUMP) { a.PX[eij] = epx; a.PY[eij] = epy; }
+      } else {
+        epx = a.PX[eij]; epy = a.PY[eij];
+      }
+      if (VEL) {
+        double ux = esum(0, kind, 0, idx), vx = esum(0, kind, 1, idx);
+        double lu = esum(0, kind, 2, idx) + esum(1, kind, 1, idx);
+        double lv = esum(0, kind, 3, idx) + esum(1, kind, 3, idx);
+        double uy = esum(1, kind, 0, idx), vy = esum(1, kind, 2, idx);
+        {  // rank-1 completion, k = M-1
+          const double exl = a.DxL[ei], e2xl = a.D2xL[ei], eyl = a.DyL[ej], e2yl = a.D2yL[ej];
+          const double ee = a.Uin[(size_t)m1 * LD + ej], fe = a.Vin[(size_t)m1 * LD + ej];
+          const double en = a.Uin[(size_t)ei * LD + m1], fn = a.Vin[(size_t)ei * LD + m1];
+          ux += exl * ee; vx += exl * fe;
+          uy += en * eyl; vy += fn * eyl;
+          lu += e2xl * ee + en * e2yl;
+          lv += e2xl * fe + fn * e2yl;
+        }
+        const double eu = a.Uin[eij], ev = a.Vin[eij];
+        const double Ru = -(eu * ux + ev * uy) - epx + a.nu * lu;
+        const double Rv = -(eu * vx + ev * vy) - epy + a.nu * lv;
+        if (DUMP) {
+          a.dump[0][eij] = ux; a.dump[1][eij] = uy; a.dump[2][eij] = vx; a.dump[3][eij] = vy;
+          a.dump[4][eij] = lu; a.dump[5][eij] = lv; a.dump[6][eij] = epx; a.dump[7][eij] = epy;
+          a.dump[8][eij] = Ru; a.dump[9][eij] = Rv;
+        } else if (LAST) {
+          const double b0 = a.U0[eij], c0v = a.V0[eij];   // boundary values never change
+          sums[PS_U02] = b0 * b0; sums[PS_V02] = c0v * c0v;
+          sums[PS_RU2] = Ru * Ru; sums[PS_RV2] = Rv * Rv;
+          sums[PS_E] = a.wx[ei] * a.wy[ej] * (b0 * b0 + c0v * c0v);
+          maxs[0] = fabs(b0); maxs[1] = fabs(c0v);
+        }
+      }
     }
   }
-  double s[NA];
-  kreduce<NA>(acc, red, lane, wv, s);
+  if (DUMP) return;
 
-  // ---- pointwise epilogue: thread owns node (i, j) -------------------------------------
-  const int ti = 4 * wv + (lane >> 4), tj = lane & 15;
-  const int i = r0 + ti, j = c0 + tj;
-  const size_t ij = (size_t)i * LD + j;
-  const bool valid = (i < M) && (j < M);
-  const bool interior = (i >= 1) && (i <= M - 2) && (j >= 1) && (j <= M - 2);
-  const double uin = a.Uin[ij], vin = a.Vin[ij];
-  double ux = s[0], vx = s[1], uy = s[2], vy = s[3], lu = s[4], lv = s[5];
-  if (a.tail) {
-    // k = M-1 lies outside the MFMA range: exact rank-1 completion of every contraction
-    const int m1 = M - 1;
-    const double dxl = a.Dx[(size_t)i * LD + m1], d2xl = a.D2x[(size_t)i * LD + m1];
-    const double dyl = a.Dy[(size_t)j * LD + m1], d2yl = a.D2y[(size_t)j * LD + m1];
-    const double ue = a.Uin[(size_t)m1 * LD + j], ve = a.Vin[(size_t)m1 * LD + j];
-    const double un = a.Uin[(size_t)i * LD + m1], vn = a.Vin[(size_t)i * LD + m1];
-    ux += dxl * ue; vx += dxl * ve;
-    uy += un * dyl; vy += vn * dyl;
-    lu += d2xl * ue + un * d2yl;
-    lv += d2xl * ve + vn * d2yl;
-  }
-  double px, py;
-  if (GP) {
-    px = valid ? s[NA - 2] : 0.0;   // T1T/T2T rows of index M-1 are zero: no completion term
-    py = valid ? s[NA - 1] : 0.0;
-    if (!DUMP) { a.PX[ij] = px; a.PY[ij] = py; }
-  } else {
-    px = a.PX[ij]; py = a.PY[ij];
-  }
-  const double Ru = -(uin * ux + vin * uy) - px + a.nu * lu;
-  const double Rv = -(uin * vx + vin * vy) - py + a.nu * lv;
-  const double Rp = -a.beta2 * (ux + vy);
-
-  if (DUMP) {
-    if (valid) {
-      a.dump[0][ij] = ux; a.dump[1][ij] = uy; a.dump[2][ij] = vx; a.dump[3][ij] = vy;
-      a.dump[4][ij] = lu; a.dump[5][ij] = lv; a.dump[6][ij] = px; a.dump[7][ij] = py;
-      a.dump[8][ij] = Ru; a.dump[9][ij] = Rv;
-      if (interior) a.dump[10][ij] = Rp;
-    }
-    return;
-  }
-
-  const double u0 = a.U0[ij], v0 = a.V0[ij];
-  double un = u0 + adt * Ru, vn = v0 + adt * Rv;
-  // walls first, lid last (sg.py:348-385): the lid row wins the two top corners
-  if (!valid) { un = 0.0; vn = 0.0; }
-  else if (j == M - 1) { un = a.ulid[i]; vn = 0.0; }
-  else if (i == 0 || i == M - 1 || j == 0) { un = 0.0; vn = 0.0; }
-  a.Uout[ij] = un;
-  a.Vout[ij] = vn;
-  if (a.Pout != nullptr) a.Pout[ij] = interior ? (a.P0[ij] + adt * Rp) : 0.0;
-
-  // transposed copies through LDS (the reduction buffer is free again after a barrier)
   __syncthreads();
-  double* tu = red;
-  double* tv = red + 16 * 17;
-  tu[ti * 17 + tj] = un;
-  tv[ti * 17 + tj] = vn;
-  __syncthreads();
-  {
+  if (owner) {
     const int tr = tid >> 4, tc = tid & 15;   // write UT[c0+tr][r0+tc] = tile[tc][tr]
-    const size_t o = (size_t)(c0 + tr) * LD + r0 + tc;
-    a.UoutT[o] = tu[tc * 17 + tr];
-    a.VoutT[o] = tv[tc * 17 + tr];
+    const size_t ot = (size_t)(c0 + tr) * LD + r0 + tc;
+    a.UoutT[ot] = tu[tc * 17 + tr];
+    a.VoutT[ot] = tv[tc * 17 + tr];
   }
-
   if (LAST) {
-    double sums[PS_NSUM];
-    double maxs[2];
-    const double du = un - u0, dv = vn - v0;
-    sums[PS_DU2] = valid ? du * du : 0.0;
-    sums[PS_DV2] = valid ? dv * dv : 0.0;
-    sums[PS_U02] = valid ? u0 * u0 : 0.0;
-    sums[PS_V02] = valid ? v0 * v0 : 0.0;
-    sums[PS_RU2] = valid ? Ru * Ru : 0.0;
-    sums[PS_RV2] = valid ? Rv * Rv : 0.0;
-    sums[PS_RP2] = interior ? Rp * Rp : 0.0;
-    sums[PS_E] = valid ? a.wx[i] * a.wy[j] * (un * un + vn * vn) : 0.0;
-    maxs[0] = fabs(un);
-    maxs[1] = fabs(vn);
-    block_reduce_store<PS_NSUM, 2>(sums, maxs, red + 2 * 16 * 17, a.partials + (size_t)blockIdx.x * LDC_NPART, lane, wv);
+    // block reduction through LDS (the accumulator region is free again): one wave per value,
+    // fixed order; ten shuffle trees per wave would cost far more than this transpose
+#pragma unroll
+    for (int q = 0; q < PS_NSUM; ++q) red[q * kStageThreads + tid] = sums[q];
+    red[PS_UMAX * kStageThreads + tid] = maxs[0];
+    red[PS_VMAX * kStageThreads + tid] = maxs[1];
+    __syncthreads();
+    double* dst = a.partials + (size_t)blockIdx.x * LDC_NPART;
+    {
+      double x = 0.0;
+#pragma unroll
+      for (int m = 0; m < kStageWaves; ++m) x += red[wv * kStageThreads + lane + 64 * m];
+      x = wave_sum(x);
+      if (lane == 0) dst[wv] = x;       // kStageWaves == PS_NSUM
+    }
+    if (wv < 2) {
+      double x = 0.0;
+#pragma unroll
+      for (int m = 0; m < kStageWaves; ++m) x = fmax(x, red[(PS_NSUM + wv) * kStageThreads + lane + 64 * m]);
+      x = wave_max(x);
+      if (lane == 0) dst[PS_NSUM + wv] = x;
+    }
+    if (blockIdx.x == 0 && tid == 0) a.ctrl[LDC_CTRL_STEP] = step0 + 1;   // one more state update done
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// finalize: ONE work-group folds the per-block partials in a fixed order.  It rides along
+// as the last block of the post launch (no launch of its own inside the iteration loop).
+//   ctrl[ITER]    iterations finalized          ctrl[STEP]    stage-4 updates completed
+//   ctrl[FLUSHED] records whose Z/P are filled  ctrl[DONE]    latch
+// Z and P of iteration n are produced AFTER its finalize (omega tiles of the same launch,
+// then the palinstrophy kernel), so they are folded one launch later ("lagged flush") from
+// parity slabs; an idempotent flush launch at the end of every enqueue closes the last record.
+// ---------------------------------------------------------------------------------------
+struct FinalArgs {
+  int nblk4, nblkZ, nblkP;   // rows in each slab
+  int with_diag, warmup, nan_guard, rec_cap;
+  int do_critical;           // 0: flush only
+  double cfl, beta2, nu, hx, hy, lid, tol;
+  const double *part4, *partZ0, *partP0;   // parity slabs: partZ0 + parity * stride
+  long long stride;
+  double* scal;
+  int* ctrl;
+  double* rec;
+};
+
+__device__ __forceinline__ double next_dt(double umax, double vmax, const FinalArgs& a) {
+  const double um = fmax(umax, a.lid), vm = fmax(vmax, 1e-10);
+  const double lx = (um + sqrt(um * um + a.beta2)) / a.hx + a.nu / (a.hx * a.hx);
+  const double ly = (vm + sqrt(vm * vm + a.beta2)) / a.hy + a.nu / (a.hy * a.hy);
+  return a.cfl / (lx + ly);
+}
+
+// all kThreads threads of one block call this; sm holds kThreads * (PS_N + 2) doubles
+__device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t) {
+  const int done = a.ctrl[LDC_CTRL_DONE], iter = a.ctrl[LDC_CTRL_ITER];
+  const int step = a.ctrl[LDC_CTRL_STEP], flushed = a.ctrl[LDC_CTRL_FLUSHED];
+  const bool flush = a.with_diag && (flushed < iter);             // record iter-1 lacks Z, P
+  const bool crit = a.do_critical && !done && (step > iter);       // iteration `iter` awaits its record
+  if (!flush && !crit) return;
+  double v[PS_N + 2];
+#pragma unroll
+  for (int q = 0; q < PS_N + 2; ++q) v[q] = 0.0;
+  if (crit) {
+    for (int r = t; r < a.nblk4; r += kThreads) {
+      const double* p = a.part4 + (size_t)r * LDC_NPART;
+#pragma unroll
+      for (int q = 0; q < PS_NSUM; ++q) v[q] += p[q];
+      v[PS_UMAX] = fmax(v[PS_UMAX], p[PS_UMAX]);
+      v[PS_VMAX] = fmax(v[PS_VMAX], p[PS_VMAX]);
+    }
+  }
+  if (flush) {
+    const int par = (iter - 1) & 1;
+    const double* pz = a.partZ0 + (size_t)par * a.stride;
+    const double* pp = a.partP0 + (size_t)par * a.stride;
+    for (int r = t; r < a.nblkZ; r += kThreads) v[PS_N] += pz[(size_t)r * LDC_NPART];
+    for (int r = t; r < a.nblkP; r += kThreads) v[PS_N + 1] += pp[(size_t)r * LDC_NPART];
+  }
+#pragma unroll
+  for (int q = 0; q < PS_N + 2; ++q) sm[q * kThreads + t] = v[q];
+  __syncthreads();
+  for (int h = kThreads / 2; h > 0; h >>= 1) {
+    if (t < h) {
+#pragma unroll
+      for (int q = 0; q < PS_N + 2; ++q) {
+        const bool is_max = (q == PS_UMAX || q == PS_VMAX);
+        const double x = sm[q * kThreads + t], y = sm[q * kThreads + t + h];
+        sm[q * kThreads + t] = is_max ? fmax(x, y) : (x + y);
+      }
+    }
+    __syncthreads();
+  }
+  if (t != 0) return;
+  double r[PS_N + 2];
+#pragma unroll
+  for (int q = 0; q < PS_N + 2; ++q) r[q] = sm[q * kThreads];
+  if (flush) {
+    double* rec = a.rec + (size_t)((iter - 1) % a.rec_cap) * LDC_REC_LEN;
+    rec[LDC_REC_Z] = 0.5 * r[PS_N];
+    rec[LDC_REC_P] = 0.5 * r[PS_N + 1];
+    a.ctrl[LDC_CTRL_FLUSHED] = iter;
+  }
+  if (crit) {
+    const double relu = sqrt(r[PS_DU2]) / (sqrt(r[PS_U02]) + 1e-12);
+    const double relv = sqrt(r[PS_DV2]) / (sqrt(r[PS_V02]) + 1e-12);
+    // Python's max(a, b) returns a unless b > a: a NaN in relv is dropped, one in relu sticks
+    const double rel = (relv > relu) ? relv : relu;
+    double* rec = a.rec + (size_t)(iter % a.rec_cap) * LDC_REC_LEN;   // `iter` = 0-based index of this iteration
+    rec[LDC_REC_REL] = rel;
+    rec[LDC_REC_RU] = sqrt(r[PS_RU2]);
+    rec[LDC_REC_RV] = sqrt(r[PS_RV2]);
+    rec[LDC_REC_RP] = sqrt(r[PS_RP2]);
+    rec[LDC_REC_E] = 0.5 * r[PS_E];
+    rec[LDC_REC_Z] = 0.0;
+    rec[LDC_REC_P] = 0.0;
+    rec[LDC_REC_DT] = a.scal[LDC_SCAL_DT];
+    a.scal[LDC_SCAL_UMAX] = r[PS_UMAX];
+    a.scal[LDC_SCAL_VMAX] = r[PS_VMAX];
+    a.scal[LDC_SCAL_DT] = next_dt(r[PS_UMAX], r[PS_VMAX], a);
+    a.ctrl[LDC_CTRL_ITER] = iter + 1;
+    if (!a.with_diag) a.ctrl[LDC_CTRL_FLUSHED] = iter + 1;      // nothing to fold for this record
+    if (iter >= a.warmup && rel < a.tol) a.ctrl[LDC_CTRL_DONE] = 1;
+    else if (a.nan_guard && !(fabs(rel) <= 1.79769313486231570815e308)) a.ctrl[LDC_CTRL_DONE] = 2;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void finalize_kernel(const FinalArgs a) {
+  __shared__ double sm[kThreads * (PS_N + 2)];
+  fin_work(a, sm, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -353,16 +662,26 @@ struct PostArgs {
   double *T1T, *T2T, *W, *WT;
   const double *wx, *wy;
   const int* ctrl;
-  double* partZ;   // one double per block (stride LDC_NPART)
-  int ignore_latch;
+  double* partZ0;  // parity slabs, one double per block (stride LDC_NPART)
+  long long stride;
+  int ungated;     // stand-alone calls: always run
+  int fin_block;   // index of the finalize block in this launch, or -1
+  FinalArgs fin;
 };
 
 __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a) {
-  __shared__ __attribute__((aligned(16))) double red[kWaves * 2 * 4 * 64];
-  if (!a.ignore_latch && a.ctrl[LDC_CTRL_DONE] != 0) return;
+  __shared__ __attribute__((aligned(16))) double red[kThreads * (PS_N + 2)];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int M = a.M, LD = a.LD, T = a.T, nt = T * T, m1 = M - 1;
   int b = (int)blockIdx.x;
+  if (b == a.fin_block) { fin_work(a.fin, red, tid); return; }
+  // After the latch nothing changes any more: once the last record is flushed every tile of
+  // this launch would reproduce bit-identical output, so the whole launch may be skipped.
+  // (Blocks may disagree while the finalize block of this very launch flips FLUSHED; that
+  // is benign for the same reason.)
+  const int step = a.ctrl[LDC_CTRL_STEP];
+  if (!a.ungated && a.ctrl[LDC_CTRL_DONE] != 0 && a.ctrl[LDC_CTRL_FLUSHED] >= step) return;
+  double* partZ = a.partZ0 + (size_t)((step > 0 ? step - 1 : 0) & 1) * a.stride;
 
   if (b < nt) {
     // ---- T1T[j][i] = sum_k P[i][k] IyF[j][k],  T2T[j][i] = sum_k P[i][k] GyF[j][k] -------
@@ -447,7 +766,7 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a) {
     a.WT[(size_t)(c0 + tr) * LD + r0 + tc] = tw[tc * 17 + tr];
     double sums[1] = {valid ? a.wx[i] * a.wy[j] * w * w : 0.0};
     double dummy[1] = {0.0};
-    block_reduce_store<1, 0>(sums, dummy, red + 16 * 17, a.partZ + (size_t)b * LDC_NPART, lane, wv);
+    block_reduce_store<1, 0>(sums, dummy, red + 16 * 17, partZ + (size_t)b * LDC_NPART, lane, wv);
     return;
   }
   b -= nt;
@@ -468,7 +787,7 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a) {
         sums[0] = a.wx[i] * a.wy[j] * w * w;
       }
     }
-    block_reduce_store<1, 0>(sums, dummy, red, a.partZ + (size_t)(nt + b) * LDC_NPART, lane, wv);
+    block_reduce_store<1, 0>(sums, dummy, red, partZ + (size_t)(nt + b) * LDC_NPART, lane, wv);
   }
 }
 
@@ -479,16 +798,19 @@ struct PalinArgs {
   int M, LD, T, tail;
   const double *Dx, *Dy, *W, *WT, *wx, *wy;
   const int* ctrl;
-  double* partP;
-  int ignore_latch;
+  double* partP0;
+  long long stride;
+  int ungated;
 };
 
 __global__ __launch_bounds__(kThreads) void palin_kernel(const PalinArgs a) {
   __shared__ __attribute__((aligned(16))) double red[kWaves * 2 * 4 * 64];
-  if (!a.ignore_latch && a.ctrl[LDC_CTRL_DONE] != 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int M = a.M, LD = a.LD, T = a.T, nt = T * T, m1 = M - 1;
   const int b = (int)blockIdx.x;
+  const int step = a.ctrl[LDC_CTRL_STEP];
+  if (!a.ungated && a.ctrl[LDC_CTRL_DONE] != 0 && a.ctrl[LDC_CTRL_FLUSHED] >= step) return;   // see post_kernel
+  double* partP = a.partP0 + (size_t)((step > 0 ? step - 1 : 0) & 1) * a.stride;
   double sums[1] = {0.0};
   double dummy[1] = {0.0};
   if (b < nt) {
@@ -526,88 +848,12 @@ __global__ __launch_bounds__(kThreads) void palin_kernel(const PalinArgs a) {
       if (lane == 0) sums[0] = a.wx[i] * a.wy[j] * (gx * gx + gy * gy);
     }
   }
-  block_reduce_store<1, 0>(sums, dummy, red, a.partP + (size_t)b * LDC_NPART, lane, wv);
+  block_reduce_store<1, 0>(sums, dummy, red, partP + (size_t)b * LDC_NPART, lane, wv);
 }
 
 // ---------------------------------------------------------------------------------------
 // finalize: one work-group folds the per-block partials in a fixed order
 // ---------------------------------------------------------------------------------------
-struct FinalArgs {
-  int nblk4, nblkZ, nblkP;   // rows in each slab
-  int with_diag, warmup, nan_guard, rec_cap;
-  double cfl, beta2, nu, hx, hy, lid, tol;
-  const double *part4, *partZ, *partP;
-  double* scal;
-  int* ctrl;
-  double* rec;
-};
-
-__device__ __forceinline__ double next_dt(double umax, double vmax, const FinalArgs& a) {
-  const double um = fmax(umax, a.lid), vm = fmax(vmax, 1e-10);
-  const double lx = (um + sqrt(um * um + a.beta2)) / a.hx + a.nu / (a.hx * a.hx);
-  const double ly = (vm + sqrt(vm * vm + a.beta2)) / a.hy + a.nu / (a.hy * a.hy);
-  return a.cfl / (lx + ly);
-}
-
-__global__ __launch_bounds__(kThreads) void finalize_kernel(const FinalArgs a) {
-  __shared__ double sm[kThreads * (PS_N + 2)];
-  if (a.ctrl[LDC_CTRL_DONE] != 0) return;
-  const int t = threadIdx.x;
-  double v[PS_N + 2];
-#pragma unroll
-  for (int q = 0; q < PS_N + 2; ++q) v[q] = 0.0;
-  for (int r = t; r < a.nblk4; r += kThreads) {
-    const double* p = a.part4 + (size_t)r * LDC_NPART;
-#pragma unroll
-    for (int q = 0; q < PS_NSUM; ++q) v[q] += p[q];
-    v[PS_UMAX] = fmax(v[PS_UMAX], p[PS_UMAX]);
-    v[PS_VMAX] = fmax(v[PS_VMAX], p[PS_VMAX]);
-  }
-  if (a.with_diag) {
-    for (int r = t; r < a.nblkZ; r += kThreads) v[PS_N] += a.partZ[(size_t)r * LDC_NPART];
-    for (int r = t; r < a.nblkP; r += kThreads) v[PS_N + 1] += a.partP[(size_t)r * LDC_NPART];
-  }
-#pragma unroll
-  for (int q = 0; q < PS_N + 2; ++q) sm[q * kThreads + t] = v[q];
-  __syncthreads();
-  for (int h = kThreads / 2; h > 0; h >>= 1) {
-    if (t < h) {
-#pragma unroll
-      for (int q = 0; q < PS_N + 2; ++q) {
-        const bool is_max = (q == PS_UMAX || q == PS_VMAX);
-        const double x = sm[q * kThreads + t], y = sm[q * kThreads + t + h];
-        sm[q * kThreads + t] = is_max ? fmax(x, y) : (x + y);
-      }
-    }
-    __syncthreads();
-  }
-  if (t == 0) {
-    double r[PS_N + 2];
-#pragma unroll
-    for (int q = 0; q < PS_N + 2; ++q) r[q] = sm[q * kThreads];
-    const double relu = sqrt(r[PS_DU2]) / (sqrt(r[PS_U02]) + 1e-12);
-    const double relv = sqrt(r[PS_DV2]) / (sqrt(r[PS_V02]) + 1e-12);
-    // Python's max(a, b) returns a unless b > a: a NaN in relv is dropped, one in relu sticks
-    const double rel = (relv > relu) ? relv : relu;
-    const int it = a.ctrl[LDC_CTRL_ITER];           // 0-based index of this iteration
-    double* rec = a.rec + (size_t)(it % a.rec_cap) * LDC_REC_LEN;
-    rec[LDC_REC_REL] = rel;
-    rec[LDC_REC_RU] = sqrt(r[PS_RU2]);
-    rec[LDC_REC_RV] = sqrt(r[PS_RV2]);
-    rec[LDC_REC_RP] = sqrt(r[PS_RP2]);
-    rec[LDC_REC_E] = 0.5 * r[PS_E];
-    rec[LDC_REC_Z] = 0.5 * r[PS_N];
-    rec[LDC_REC_P] = 0.5 * r[PS_N + 1];
-    rec[LDC_REC_DT] = a.scal[LDC_SCAL_DT];
-    a.scal[LDC_SCAL_UMAX] = r[PS_UMAX];
-    a.scal[LDC_SCAL_VMAX] = r[PS_VMAX];
-    a.scal[LDC_SCAL_DT] = next_dt(r[PS_UMAX], r[PS_VMAX], a);
-    a.ctrl[LDC_CTRL_ITER] = it + 1;
-    if (it >= a.warmup && rel < a.tol) a.ctrl[LDC_CTRL_DONE] = 1;
-    else if (a.nan_guard && !(fabs(rel) <= 1.79769313486231570815e308)) a.ctrl[LDC_CTRL_DONE] = 2;
-  }
-}
-
 // dt of the very first iteration: max |u|, max |v| over the whole padded arrays
 __global__ __launch_bounds__(kThreads) void prime_kernel(const double* U, const double* V, int n, FinalArgs a) {
   __shared__ double sm[2 * kWaves];
@@ -730,6 +976,7 @@ __global__ __launch_bounds__(kThreads) void mfma_peak_kernel(double* sink, int i
   v4d c[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) c[q] = (v4d){0.0, 0.0, 0.0, (double)q};
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) c[q] = MFMA_F64(a, b, c[q]);
@@ -737,7 +984,12 @@ __global__ __launch_bounds__(kThreads) void mfma_peak_kernel(double* sink, int i
   double s = 0.0;
 #pragma unroll
   for (int q = 0; q < 8; ++q) s += c[q][0] + c[q][1] + c[q][2] + c[q][3];
-  if (s == 123.456) sink[blockIdx.x * kThreads + l] = s;
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (s == 123.456) sink[blockIdx.x * kThreads + l + 2] = s;
+  if (blockIdx.x == 0 && l == 0) {   // shader cycles and 100 MHz ticks spent in the loop
+    sink[0] = (double)(t1 - t0);
+    sink[1] = (double)(r1 - r0);
+  }
 }
 
 }  // namespace
@@ -751,6 +1003,7 @@ struct ldc_solver {
   int n_edge_blocks; // blocks of 4 edge nodes (tail case), else 0
   int n_pedge_blocks;
   int iters_per_graph;
+  int ablate;
   hipGraphExec_t graph[2];   // [with_diagnostics]
   hipStream_t capture_stream;
 };
@@ -777,7 +1030,9 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
   a.U0 = p.U; a.V0 = p.V; a.P0 = p.P;
   a.T1T = p.T1T; a.T2T = p.T2T; a.PX = p.PX; a.PY = p.PY;
   a.ulid = p.ulid; a.wx = p.wx; a.wy = p.wy; a.scal = p.scal; a.ctrl = p.ctrl;
+  a.DxL = p.DxL; a.D2xL = p.D2xL; a.DyL = p.DyL; a.D2yL = p.D2yL;
   a.partials = p.partials;
+  a.ablate = s->ablate;
   // ping-pong: 0: S0 -> A, 1: A -> B, 2: B -> A, 3: A -> S0 (in place)
   const double *in[4][4] = {{p.U, p.UT, p.V, p.VT}, {p.UA, p.UAT, p.VA, p.VAT},
                             {p.UB, p.UBT, p.VB, p.VBT}, {p.UA, p.UAT, p.VA, p.VAT}};
@@ -789,20 +1044,43 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
   return a;
 }
 
-int launch_stage(const ldc_solver* s, int k, hipStream_t st) {
-  const StageArgs a = make_stage_args(s, k);
-  const dim3 blk(kThreads);
-  if (k == 0) {
-    hipLaunchKernelGGL((stage_kernel<true, false, false>), dim3(s->nt), blk, 0, st, a);
-  } else if (k < 3) {
-    hipLaunchKernelGGL((stage_kernel<false, false, false>), dim3(s->nt), blk, 0, st, a);
-  } else {
-    hipLaunchKernelGGL((stage_kernel<false, true, false>), dim3(s->nt + s->n_edge_blocks), blk, 0, st, a);
+template <bool GP, bool LAST, bool DUMP>
+int launch_stage_variant(const StageArgs& a, int nt, hipStream_t st) {
+  static bool attr_set = false;   // dynamic LDS above 64 KiB must be enabled once per kernel
+  auto kern = stage_kernel<GP, LAST, DUMP>;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)StageLds<GP>::BYTES));
+    attr_set = true;
   }
+  hipLaunchKernelGGL(kern, dim3(nt), dim3(kStageThreads), StageLds<GP>::BYTES, st, a);
   return (int)hipGetLastError();
 }
 
-int launch_post(const ldc_solver* s, const double* P, int do_omega, int ignore_latch, hipStream_t st) {
+int launch_stage(ldc_solver* s, int k, hipStream_t st) {
+  const StageArgs a = make_stage_args(s, k);
+  if (k == 0) return launch_stage_variant<true, false, false>(a, s->nt, st);
+  if (k < 3) return launch_stage_variant<false, false, false>(a, s->nt, st);
+  return launch_stage_variant<false, true, false>(a, s->nt, st);
+}
+
+FinalArgs make_final_args(const ldc_solver* s, int with_diag, int do_critical) {
+  const ldc_problem& p = s->p;
+  FinalArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nblk4 = s->nt; a.nblkZ = s->nt + s->n_edge_blocks; a.nblkP = a.nblkZ;
+  a.with_diag = with_diag; a.warmup = p.warmup; a.nan_guard = p.nan_guard; a.rec_cap = p.rec_cap;
+  a.do_critical = do_critical;
+  a.cfl = p.cfl; a.beta2 = p.beta2; a.nu = p.nu; a.hx = p.hx_min; a.hy = p.hy_min;
+  a.lid = p.lid_speed; a.tol = p.tol;
+  a.part4 = p.partials; a.partZ0 = p.partials + p.partials_stride; a.partP0 = p.partials + 3 * p.partials_stride;
+  a.stride = p.partials_stride;
+  a.scal = p.scal; a.ctrl = p.ctrl; a.rec = p.rec;
+  return a;
+}
+
+// T1T/T2T (+ omega tiles) (+ the finalize block); `loop` = inside the iteration loop
+int launch_post(const ldc_solver* s, const double* P, int do_omega, int loop, int with_diag, hipStream_t st) {
   const ldc_problem& p = s->p;
   PostArgs a;
   memset(&a, 0, sizeof(a));
@@ -810,51 +1088,46 @@ int launch_post(const ldc_solver* s, const double* P, int do_omega, int ignore_l
   a.Dx = p.Dx; a.Dy = p.Dy; a.IyF = p.IyF; a.GyF = p.GyF;
   a.U = p.U; a.V = p.V; a.VT = p.VT; a.P = P;
   a.T1T = p.T1T; a.T2T = p.T2T; a.W = p.W; a.WT = p.WT; a.wx = p.wx; a.wy = p.wy;
-  a.ctrl = p.ctrl; a.partZ = p.partials + p.partials_stride; a.ignore_latch = ignore_latch;
+  a.ctrl = p.ctrl; a.partZ0 = p.partials + p.partials_stride; a.stride = p.partials_stride;
+  a.ungated = loop ? 0 : 1;
   int grid = s->nt + s->n_pedge_blocks;
   if (do_omega) grid += s->nt + s->n_edge_blocks;
+  a.fin_block = -1;
+  if (loop) {
+    a.fin_block = grid++;
+    a.fin = make_final_args(s, with_diag, 1);
+  }
   hipLaunchKernelGGL(post_kernel, dim3(grid), dim3(kThreads), 0, st, a);
   return (int)hipGetLastError();
 }
 
-int launch_palin(const ldc_solver* s, int ignore_latch, hipStream_t st) {
+int launch_palin(const ldc_solver* s, int loop, hipStream_t st) {
   const ldc_problem& p = s->p;
   PalinArgs a;
   memset(&a, 0, sizeof(a));
   a.M = p.M; a.LD = p.LD; a.T = p.T; a.tail = p.tail;
   a.Dx = p.Dx; a.Dy = p.Dy; a.W = p.W; a.WT = p.WT; a.wx = p.wx; a.wy = p.wy;
-  a.ctrl = p.ctrl; a.partP = p.partials + 2 * p.partials_stride; a.ignore_latch = ignore_latch;
+  a.ctrl = p.ctrl; a.partP0 = p.partials + 3 * p.partials_stride; a.stride = p.partials_stride;
+  a.ungated = loop ? 0 : 1;
   hipLaunchKernelGGL(palin_kernel, dim3(s->nt + s->n_edge_blocks), dim3(kThreads), 0, st, a);
   return (int)hipGetLastError();
 }
 
-FinalArgs make_final_args(const ldc_solver* s, int with_diag) {
-  const ldc_problem& p = s->p;
-  FinalArgs a;
-  memset(&a, 0, sizeof(a));
-  a.nblk4 = s->nt + s->n_edge_blocks; a.nblkZ = a.nblk4; a.nblkP = a.nblk4;
-  a.with_diag = with_diag; a.warmup = p.warmup; a.nan_guard = p.nan_guard; a.rec_cap = p.rec_cap;
-  a.cfl = p.cfl; a.beta2 = p.beta2; a.nu = p.nu; a.hx = p.hx_min; a.hy = p.hy_min;
-  a.lid = p.lid_speed; a.tol = p.tol;
-  a.part4 = p.partials; a.partZ = p.partials + p.partials_stride; a.partP = p.partials + 2 * p.partials_stride;
-  a.scal = p.scal; a.ctrl = p.ctrl; a.rec = p.rec;
-  return a;
-}
-
-int launch_finalize(const ldc_solver* s, int with_diag, hipStream_t st) {
-  const FinalArgs a = make_final_args(s, with_diag);
+int launch_finalize(const ldc_solver* s, int with_diag, int do_critical, hipStream_t st) {
+  const FinalArgs a = make_final_args(s, with_diag, do_critical);
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kThreads), 0, st, a);
   return (int)hipGetLastError();
 }
 
-// one iteration of base.py:243-313 as launches on `st`
-int launch_iteration(const ldc_solver* s, int with_diag, hipStream_t st) {
+// one iteration of base.py:243-313 as launches on `st`; the record's Z/P are folded by the
+// next iteration's post launch or by the flush at the end of ldc_solver_enqueue
+int launch_iteration(ldc_solver* s, int with_diag, hipStream_t st) {
   int e;
   for (int k = 0; k < 4; ++k)
     if ((e = launch_stage(s, k, st)) != 0) return e;
-  if ((e = launch_post(s, s->p.P, with_diag, 0, st)) != 0) return e;
-  if (with_diag && (e = launch_palin(s, 0, st)) != 0) return e;
-  return launch_finalize(s, with_diag, st);
+  if ((e = launch_post(s, s->p.P, with_diag, 1, with_diag, st)) != 0) return e;
+  if (with_diag && (e = launch_palin(s, 1, st)) != 0) return e;
+  return 0;
 }
 
 int build_graph(ldc_solver* s, int with_diag) {
@@ -907,6 +1180,7 @@ int ldc_solver_create(const ldc_problem* d, ldc_solver** out) {
   if (d->tail != ((16 * d->T == d->M - 1) ? 1 : 0)) return LDC_E_ARG;
   if (d->rec_cap < 1 || d->stage_pressure != 0) return LDC_E_ARG;
   const void* req[] = {d->Dx, d->D2x, d->Dy, d->D2y, d->IxF, d->GxF, d->IyF, d->GyF, d->wx, d->wy, d->ulid,
+                       d->DxL, d->D2xL, d->DyL, d->D2yL,
                        d->U, d->UT, d->V, d->VT, d->P, d->UA, d->UAT, d->VA, d->VAT, d->UB, d->UBT, d->VB,
                        d->VBT, d->T1T, d->T2T, d->PX, d->PY, d->W, d->WT, d->partials, d->scal, d->ctrl, d->rec};
   for (const void* q : req) if (bad_ptr(q)) return LDC_E_ARG;
@@ -918,6 +1192,7 @@ int ldc_solver_create(const ldc_problem* d, ldc_solver** out) {
   s->n_pedge_blocks = d->tail ? (d->M + kWaves - 1) / kWaves : 0;
   if (d->partials_stride < (int64_t)(s->nt + s->n_edge_blocks) * LDC_NPART) { delete s; return LDC_E_ARG; }
   s->iters_per_graph = 32;
+  s->ablate = 0;
   s->graph[0] = s->graph[1] = nullptr;
   s->capture_stream = nullptr;
   *out = s;
@@ -939,6 +1214,12 @@ int ldc_solver_set_graph_iters(ldc_solver* s, int n) {
   return 0;
 }
 
+int ldc_debug_ablate(ldc_solver* s, int mask) {
+  if (!s) return LDC_E_STATE;
+  s->ablate = mask;
+  return 0;
+}
+
 int ldc_stage(ldc_solver* s, int k, void* stream) {
   if (!s) return LDC_E_STATE;
   if (k < 0 || k > 3) return LDC_E_ARG;
@@ -949,26 +1230,29 @@ int ldc_pressure_transform(ldc_solver* s, int which, void* stream) {
   if (!s) return LDC_E_STATE;
   const double* P = which == 0 ? s->p.P : which == 1 ? s->p.PA : which == 2 ? s->p.PB : nullptr;
   if (!P) return LDC_E_ARG;
-  return launch_post(s, P, 0, 1, as_stream(stream));
+  return launch_post(s, P, 0, 0, 0, as_stream(stream));
 }
 
 int ldc_diagnostics(ldc_solver* s, void* stream) {
   if (!s) return LDC_E_STATE;
-  int e = launch_post(s, s->p.P, 1, 1, as_stream(stream));
+  int e = launch_post(s, s->p.P, 1, 0, 0, as_stream(stream));
   if (e) return e;
-  return launch_palin(s, 1, as_stream(stream));
+  return launch_palin(s, 0, as_stream(stream));
 }
 
 int ldc_finalize(ldc_solver* s, int with_diag, void* stream) {
   if (!s) return LDC_E_STATE;
-  return launch_finalize(s, with_diag ? 1 : 0, as_stream(stream));
+  // stand-alone form: close the iteration, then fold its Z/P right away
+  int e = launch_finalize(s, with_diag ? 1 : 0, 1, as_stream(stream));
+  if (e || !with_diag) return e;
+  return launch_finalize(s, 1, 0, as_stream(stream));
 }
 
 int ldc_prime(ldc_solver* s, void* stream) {
   if (!s) return LDC_E_STATE;
-  int e = launch_post(s, s->p.P, 0, 1, as_stream(stream));
+  int e = launch_post(s, s->p.P, 0, 0, 0, as_stream(stream));
   if (e) return e;
-  const FinalArgs a = make_final_args(s, 0);
+  const FinalArgs a = make_final_args(s, 0, 0);
   hipLaunchKernelGGL(prime_kernel, dim3(1), dim3(kThreads), 0, as_stream(stream), s->p.U, s->p.V,
                      s->p.LD * s->p.LD, a);
   return (int)hipGetLastError();
@@ -988,7 +1272,8 @@ int ldc_solver_enqueue(ldc_solver* s, int n_iters, int with_diag, void* stream) 
     }
   }
   for (; left > 0; --left) { int e = launch_iteration(s, with_diag, st); if (e) return e; }
-  return 0;
+  // close the last record (idempotent: folds Z/P only if a record is still open)
+  return with_diag ? launch_finalize(s, 1, 0, st) : 0;
 }
 
 int ldc_residual_debug(ldc_solver* s, int which, double* const out[11], void* stream) {
@@ -996,12 +1281,11 @@ int ldc_residual_debug(ldc_solver* s, int which, double* const out[11], void* st
   for (int q = 0; q < 11; ++q) if (!out[q]) return LDC_E_ARG;
   if (which < 0 || which > 2) return LDC_E_ARG;
   hipStream_t st = as_stream(stream);
-  int e = launch_post(s, s->p.P, 0, 1, st);   // SG differentiates p^n whatever the stage (Q1)
+  int e = launch_post(s, s->p.P, 0, 0, 0, st);   // SG differentiates p^n whatever the stage (Q1)
   if (e) return e;
   StageArgs a = make_stage_args(s, which == 0 ? 0 : which == 1 ? 1 : 2);
   for (int q = 0; q < 11; ++q) a.dump[q] = out[q];
-  hipLaunchKernelGGL((stage_kernel<true, false, true>), dim3(s->nt + s->n_edge_blocks), dim3(kThreads), 0, st, a);
-  return (int)hipGetLastError();
+  return launch_stage_variant<true, false, true>(a, s->nt, st);
 }
 
 int ldc_gemm_nt(const double* A, const double* B, double* C, int R16, int K16, int LD, int transpose_out,

@@ -29,6 +29,7 @@ class Problem(C.Structure):
         + [(n, C.c_int32) for n in ("warmup", "nan_guard", "stage_pressure", "rec_cap")]
         + [(n, _dp) for n in (
             "Dx", "D2x", "Dy", "D2y", "IxF", "GxF", "IyF", "GyF", "wx", "wy", "ulid",
+            "DxL", "D2xL", "DyL", "D2yL",
             "U", "UT", "V", "VT", "P",
             "UA", "UAT", "VA", "VAT", "PA",
             "UB", "UBT", "VB", "VBT", "PB",
@@ -51,6 +52,9 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64.so.7; import it FIRST so that this library binds to the
+    # runtime that owns torch's device pointers and streams (one HIP runtime per process).
+    import torch  # noqa: F401
     if not LIB_PATH.exists():
         raise LdcError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -73,6 +77,7 @@ def lib() -> C.CDLL:
     L.ldc_gemm_nt.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
     L.ldc_poisson_fastdiag.argtypes = [_dp] * 10 + [C.c_int, C.c_int, _dp]
     L.ldc_vortex_extrema.argtypes = [_dp, _dp, _dp, _dp, C.c_int, C.c_int, _dp, _dp, _dp]
+    L.ldc_debug_ablate.argtypes = [_dp, C.c_int]
     L.ldc_mfma_selftest.argtypes = [_dp, _dp, _dp, _dp]
     L.ldc_mfma_peak.argtypes = [_dp, C.c_int, C.c_int, _dp]
     for name in EXPORTS:
@@ -87,7 +92,7 @@ EXPORTS = (
     "ldc_version", "ldc_error_string", "ldc_device_check", "ldc_solver_create", "ldc_solver_destroy",
     "ldc_stage", "ldc_pressure_transform", "ldc_diagnostics", "ldc_finalize", "ldc_prime",
     "ldc_solver_enqueue", "ldc_solver_set_graph_iters", "ldc_residual_debug", "ldc_gemm_nt",
-    "ldc_poisson_fastdiag", "ldc_vortex_extrema", "ldc_mfma_selftest", "ldc_mfma_peak",
+    "ldc_poisson_fastdiag", "ldc_vortex_extrema", "ldc_mfma_selftest", "ldc_mfma_peak", "ldc_debug_ablate",
 )
 
 

@@ -123,13 +123,13 @@ class SGSolver(LidDrivenCavitySolver):
         LD, M = self.LD, self.M
         self._mats = torch.zeros((len(_MAT_NAMES), LD, LD), dtype=torch.float64, device=dev)
         self.d = {n: self._mats[k] for k, n in enumerate(_MAT_NAMES)}
-        self._vecs = torch.zeros((8, LD), dtype=torch.float64, device=dev)
-        for k, n in enumerate(("wx", "wy", "ulid", "x", "y", "lamx", "lamy")):
+        self._vecs = torch.zeros((12, LD), dtype=torch.float64, device=dev)
+        for k, n in enumerate(("wx", "wy", "ulid", "x", "y", "lamx", "lamy", "DxL", "D2xL", "DyL", "D2yL")):
             self.d[n] = self._vecs[k]
         nt = self.T * self.T
         n_edge = (2 * M - 1 + 3) // 4 if self.tail else 0
         self._part_stride = (nt + n_edge) * L.NPART
-        self.d["partials"] = torch.zeros(4 * self._part_stride, dtype=torch.float64, device=dev)
+        self.d["partials"] = torch.zeros(5 * self._part_stride, dtype=torch.float64, device=dev)
         self.d["scal"] = torch.zeros(L.SCAL_LEN, dtype=torch.float64, device=dev)
         self.d["ctrl"] = torch.zeros(L.CTRL_LEN, dtype=torch.int32, device=dev)
         self.rec_cap = max(1, int(self.params.check_every))
@@ -148,7 +148,9 @@ class SGSolver(LidDrivenCavitySolver):
                         ("IxF", IxF), ("GxF", self.Dx_1d @ IxF), ("IyF", IyF), ("GyF", self.Dy_1d @ IyF)):
             up(name, a)
         for name, v in (("wx", self.w_x), ("wy", self.w_y), ("ulid", self.u_lid),
-                        ("x", self.x_nodes), ("y", self.y_nodes)):
+                        ("x", self.x_nodes), ("y", self.y_nodes),
+                        ("DxL", self.Dx_1d[:, -1]), ("D2xL", self.Dxx_1d[:, -1]),
+                        ("DyL", self.Dy_1d[:, -1]), ("D2yL", self.Dyy_1d[:, -1])):
             pad = np.zeros(LD); pad[:M] = v
             self.d[name].copy_(torch.from_numpy(pad))
 

@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- steady-state pseudo-time-steps/s of the spectral LDC hot path on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE JSON line.
+
+* workload  : BASELINE.json configs[2] -- solver=spectral (SG), N=256, Re=1000, fp64,
+              CFL=1.5, beta^2=5, cosine lid smoothing 0.15, fluid initially at rest.
+* a "step"  : one iteration of LidDrivenCavitySolver.solve (reference base.py:243-313):
+              adaptive dt, 4 RK stages with BCs, change norms, residual norms and the
+              E/Z/P diagnostics -- everything the reference does per iteration.  The
+              step()-only rate (no E/Z/P) is reported beside it as `step_only_value`.
+* N > 1     : one process per GPU, each rank advances its own independent trial (the
+              sweep axis of the reference; no data-path collective), `value` is the sum
+              over ranks of K / max-over-ranks(time): "weak" scaling.
+* roofline  : dominant kernel = the fused RK-stage kernel.  `achieved` = necessary
+              flops per launch (68 M^3 per step / 4 launches = 17 M^3) over
+              the mean launch time measured with HIP events around bursts of full RK
+              steps on the launch stream; `peak` = 78.6 TFLOP/s fp64 matrix (AMD spec;
+              the in-run MFMA issue-rate measurement is reported as `peak_measured`).
+* cpu_baseline : the NumPy oracle (a port of the reference, pinned to its golden vectors)
+              timed on this host's cores for a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+for p in (str(ROOT), str(ROOT / "02689-advancednumericalalgorithmp3_amd" / "src")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+WORKLOAD = dict(N=256, Re=1000.0)
+PEAK_FP64_MFMA_TFLOPS = 78.6     # AMD MI355X datasheet: FP64 matrix (= 128 flop/clk/CU * 256 CU * 2.4 GHz)
+
+
+def flops_per_step(N: int, diagnostics: bool) -> float:
+    """Necessary flops of one SG iteration."""
+    M, Mi = N + 1, N - 1
+    f = 68.0 * M**3 + 2.0 * M * Mi * (M + Mi)
+    if diagnostics:
+        f += 8.0 * M**3
+    return f
+
+
+def make_solver(N, Re, device):
+    from solvers.spectral.sg import SGSolver
+    return SGSolver(name="spectral", Re=Re, lid_velocity=1.0, Lx=1.0, Ly=1.0, nx=N, ny=N,
+                    tolerance=0.0, max_iterations=10**9, basis_type="chebyshev", CFL=1.5,
+                    beta_squared=5.0, corner_treatment="smoothing", corner_smoothing=0.15,
+                    multigrid="none", device=device, check_every=8192, graph_iters=32)
+
+
+def timed_iterations(s, K, diagnostics, barrier):
+    """Enqueue exactly K iterations between two host syncs; returns seconds (host clock and events)."""
+    import torch
+    from solvers.spectral import ldc_lib as L
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    L.check(L.lib().ldc_solver_enqueue(s._handle, K, int(diagnostics), L.stream_ptr()), "enqueue")
+    e1.record()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    return t1 - t0, e0.elapsed_time(e1) * 1e-3
+
+
+def stage_kernel_time(s, bursts=20, steps_per_burst=50):
+    """Mean duration of one RK-stage launch: HIP events around bursts of stage launches only."""
+    import torch
+    from solvers.spectral import ldc_lib as L
+    lib, h, st = L.lib(), s._handle, L.stream_ptr()
+    times = []
+    for _ in range(bursts):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps_per_burst):
+            for k in range(4):
+                lib.ldc_stage(h, k, st)
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) * 1e-3 / (4 * steps_per_burst))
+    times.sort()
+    return times[len(times) // 2]
+
+
+def mfma_peak_measured():
+    """fp64 MFMA issue rate of the whole chip (8 independent accumulators per wave)."""
+    import torch
+    from solvers.spectral import ldc_lib as L
+    grid, iters = 256 * 8, 4000
+    sink = torch.zeros(grid * 256, dtype=torch.float64, device="cuda")
+    lib, st = L.lib(), L.stream_ptr()
+    lib.ldc_mfma_peak(sink.data_ptr(), 100, grid, st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    lib.ldc_mfma_peak(sink.data_ptr(), iters, grid, st)
+    e1.record()
+    torch.cuda.synchronize()
+    flops = grid * 4 * iters * 8 * 2048.0
+    return flops / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
+def cpu_baseline(N, Re, budget_s=12.0):
+    """The oracle's full solve() iteration timed on the host cores (bounded sample)."""
+    import numpy as np
+    from oracle.ldc_oracle import OracleSG
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([d.get("num_threads", 1) for d in threadpool_info() if d.get("user_api") == "blas"] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    o = OracleSG(N, Re)
+    up, vp = o.u.copy(), o.v.copy()
+
+    def one():
+        nonlocal up, vp
+        o.step()
+        np.linalg.norm(o.u - up); np.linalg.norm(o.v - vp); np.linalg.norm(up); np.linalg.norm(vp)
+        o.residual_norms(); o.energy(); o.enstrophy(); o.palinstrophy()
+        up, vp = o.u.copy(), o.v.copy()
+
+    for _ in range(3):
+        one()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="steps/s", cores=int(threads), kind="port",
+                sample=f"{n} full solve() iterations (step + norms + E/Z/P) of the NumPy oracle at "
+                       f"N={N}, Re={Re:g} from rest, {dt:.1f} s, OpenBLAS {threads} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--N", type=int, default=WORKLOAD["N"])
+    ap.add_argument("--Re", type=float, default=WORKLOAD["Re"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    import __graft_entry__ as g
+    if rank == 0:
+        g.build()
+    barrier()
+    g._paths()
+
+    s = make_solver(a.N, a.Re, f"cuda:{local}")
+    s._begin(0.0)
+    # warm-up (also instantiates both hipGraphs)
+    timed_iterations(s, max(a.warmup, 64), True, barrier)
+    timed_iterations(s, 64, False, barrier)
+
+    wall, ev = timed_iterations(s, a.steps, True, barrier)
+    wall_so, _ = timed_iterations(s, a.steps, False, barrier)
+    if dist is not None:
+        t = torch.tensor([wall, wall_so], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, wall_so = float(t[0]), float(t[1])
+    ctrl = s.d["ctrl"].cpu().numpy()
+    assert int(ctrl[0]) == 0, "latch fired during the bench (tolerance is 0: must not happen)"
+    rec = s.d["rec"].cpu().numpy()
+    assert bool((rec == rec).all()), "non-finite history record: the timed run diverged"
+
+    out = None
+    if rank == 0:
+        t_stage = stage_kernel_time(s)
+        M = a.N + 1
+        f_launch = 17.0 * M**3
+        achieved = f_launch / t_stage / 1e12
+        peak_meas = mfma_peak_measured()
+        out = {
+            "metric": "steady-state time-steps/sec at N=256 Re=1000",
+            "value": world * a.steps / wall, "unit": "steps/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * wall / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"solver=spectral (SG) N={a.N} Re={a.Re:g} fp64, full solve() iteration "
+                                   "(dt, 4 RK stages + BCs, change/residual norms, E/Z/P), fluid from rest",
+                       "N": a.N, "Re": a.Re, "CFL": 1.5, "beta_squared": 5.0, "corner_smoothing": 0.15,
+                       "trials_per_gpu": 1, "parallelism": f"{world} independent trial(s), one per GPU"},
+            "step_only_value": world * a.steps / wall_so, "step_only_ms": 1e3 * wall_so / a.steps,
+            "event_ms_per_step": 1e3 * ev / a.steps,
+            "iteration_tflops": flops_per_step(a.N, True) * a.steps / wall / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "stage_kernel (fused RK stage)", "achieved": achieved,
+                         "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
+                         "traffic": None, "flops_per_launch": f_launch, "launch_us": t_stage * 1e6,
+                         "peak_measured": peak_meas},
+        }
+        if world == 1 and not a.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(a.N, a.Re)
+            out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        else:
+            out["cpu_baseline"] = None
+    s.close()
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

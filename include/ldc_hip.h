@@ -52,7 +52,9 @@ enum {
 /* ctrl[] (int32) slots */
 enum {
   LDC_CTRL_DONE      = 0, /* latch: 1 converged, 2 non-finite; later launches are no-ops */
-  LDC_CTRL_ITER      = 1, /* completed iterations                                       */
+  LDC_CTRL_ITER      = 1, /* iterations finalized (records written)                     */
+  LDC_CTRL_STEP      = 2, /* stage-4 state updates completed                            */
+  LDC_CTRL_FLUSHED   = 3, /* records whose Z/P slots have been folded                   */
   LDC_CTRL_LEN       = 8
 };
 
@@ -89,6 +91,7 @@ typedef struct ldc_problem {
   const double *IyF, *GyF;  /* Interp_y embedded;                  Dy @ IyF  (sg.py:210, 270-276) */
   const double *wx, *wy;    /* quadrature weights, length LD       (sg.py:489-490)     */
   const double *ulid;       /* lid profile u_lid(x_i), length LD   (corner.py:80-112)  */
+  const double *DxL, *D2xL, *DyL, *D2yL; /* column M-1 of Dx, D2x, Dy, D2y as contiguous length-LD vectors */
   /* state phi^n and its transposed copies                                              */
   double *U, *UT, *V, *VT, *P;
   /* RK stage buffers (sg.py:438-442), ping-pong A/B                                    */
@@ -99,7 +102,7 @@ typedef struct ldc_problem {
   /* diagnostics: vorticity and its transpose                                           */
   double *W, *WT;
   /* reductions / control                                                               */
-  double  *partials;  /* (T*T + edge blocks) * LDC_NPART doubles per producing kernel, 4 slabs */
+  double  *partials;  /* 5 slabs of partials_stride doubles: stage 4 | Z parity 0,1 | P parity 0,1 */
   int64_t  partials_stride; /* doubles between slabs                                    */
   double  *scal;      /* LDC_SCAL_LEN doubles                                           */
   int32_t *ctrl;      /* LDC_CTRL_LEN int32                                             */
@@ -161,6 +164,10 @@ int ldc_poisson_fastdiag(const double *Qx, const double *Qxinv, const double *Qy
 /* out_val[5], out_idx[5] (flat index ix*LD+iy): 0 primary, 1 |omega| max, 2 BR, 3 BL, 4 TL */
 int ldc_vortex_extrema(const double *Psi, const double *W, const double *x, const double *y,
                        int M, int LD, double *out_val, int32_t *out_idx, void *stream);
+
+/* timing experiments only (results are WRONG while set): bit 0 skips the MFMAs, bit 1 the   */
+/* operand loads of the stage kernel                                                       */
+int ldc_debug_ablate(ldc_solver *s, int mask);
 
 /* hardware self-test: D = A(16x4) * B(4x16) with the f64 MFMA; used by tests to pin the  */
 /* operand / result lane maps                                                             */
