@@ -16,6 +16,7 @@ from abc import ABC, abstractmethod
 
 import numpy as np
 
+from . import validation as _val
 from .datastructures import Fields, Metrics, TimeSeries, _VORTEX_KEYS
 
 log = logging.getLogger(__name__)
@@ -120,3 +121,99 @@ class LidDrivenCavitySolver(ABC):
             final_enstrophy=float(last[ZN]) if (last is not None and with_diag) else 0.0,
             final_palinstrophy=float(last[PN]) if (last is not None and with_diag) else 0.0,
             **{k: float(vortex.get(k, 0.0)) for k in _VORTEX_KEYS})
+
+    # ---- validation against stored FV solutions (reference base.py:970-1054, 1122-1160) -----
+    def _evaluate_at_points(self, x: np.ndarray, y: np.ndarray):
+        """Bilinear evaluation of (u, v) on the tensor grid of ``self.fields``; NaN outside."""
+        from scipy.interpolate import RegularGridInterpolator
+        xs, ys = np.sort(np.unique(self.fields.x)), np.sort(np.unique(self.fields.y))
+        order = np.lexsort((self.fields.x, self.fields.y))          # y slow, x fast
+        pts = np.column_stack([y, x])
+        out = []
+        for f in (self.fields.u, self.fields.v):
+            grid = f[order].reshape(ys.size, xs.size)
+            out.append(RegularGridInterpolator((ys, xs), grid, method="linear", bounds_error=False,
+                                               fill_value=np.nan)(pts))
+        return out[0], out[1]
+
+    @staticmethod
+    def _load_reference_solution(directory):
+        """(x, y, u, v) of a stored FV solution: the reference's ``solution.vts`` or the compact npz."""
+        from pathlib import Path
+        d = Path(directory)
+        if (d / "solution.vts").exists():
+            from .vtkio import read_vts
+            g = read_vts(d / "solution.vts")
+            return g["points"][:, 0], g["points"][:, 1], g["point_data"]["u"], g["point_data"]["v"]
+        if (d / "solution.npz").exists():
+            g = np.load(d / "solution.npz")
+            return g["x"], g["y"], g["u"], g["v"]
+        return None
+
+    def compute_validation_errors(self, reference_dir: str = "data/validation/fv", save_plots: bool = False) -> dict:
+        """Relative L2 errors of u, v against the FV solutions at their 128 x 128 cell centres.
+
+        Like the reference (quirk Q9) the argument is ignored: both ``fv`` and ``fv-regu`` under
+        ``data/validation`` are compared (CWD first, then the packaged copies)."""
+        res = {}
+        Re = int(self.params.Re)
+        base = _val.find_data_dir()
+        for sub, suffix in (("fv", ""), ("fv-regu", "_regu")):
+            ref = self._load_reference_solution(base / sub / f"Re{Re}")
+            if ref is None:
+                continue
+            rx, ry, ru, rv = ref
+            cu, cv = self._evaluate_at_points(rx, ry)
+            eps = 1e-10
+            ok = ((rx > eps) & (rx < self.params.Lx - eps) & (ry > eps) & (ry < self.params.Ly - eps)
+                  & ~(np.isnan(cu) | np.isnan(cv)))
+            res[f"u_L2_error{suffix}"] = float(np.linalg.norm(cu[ok] - ru[ok]) / (np.linalg.norm(ru[ok]) + 1e-12))
+            res[f"v_L2_error{suffix}"] = float(np.linalg.norm(cv[ok] - rv[ok]) / (np.linalg.norm(rv[ok]) + 1e-12))
+        return res
+
+    def ghia_error(self) -> dict:
+        """Centreline error against Ghia et al. 1982 (SURVEY.md 8d Metric 2)."""
+        M = int(round(np.sqrt(self.fields.x.size)))
+        x, y = self.fields.x.reshape(M, M)[:, 0], self.fields.y.reshape(M, M)[0, :]
+        return _val.ghia_centerline_error(x, y, self.fields.u.reshape(M, M), self.fields.v.reshape(M, M),
+                                          int(self.params.Re))
+
+    def validation_table(self) -> list:
+        return _val.botella_table(self.metrics, int(self.params.Re))
+
+    def mlflow_log_validation_table(self, reference_csv: str = None):
+        """Rows are always returned; they go to MLflow only when it is importable and a run is active."""
+        rows = self.validation_table()
+        try:
+            import mlflow
+            import pandas as pd
+            if rows and mlflow.active_run():
+                mlflow.log_table(pd.DataFrame(rows), artifact_file="validation_metrics.json")
+        except ImportError:
+            pass
+        return rows
+
+    # ---- VTS export (reference base.py:464-549) ---------------------------------------------------
+    def to_vtk(self):
+        from scipy.interpolate import RectBivariateSpline
+        from .vtkio import StructuredGridFile
+        xs, ys = np.sort(np.unique(self.fields.x)), np.sort(np.unique(self.fields.y))
+        order = np.lexsort((self.fields.x, self.fields.y))
+        U, V, P = (f[order].reshape(ys.size, xs.size) for f in (self.fields.u, self.fields.v, self.fields.p))
+        g = StructuredGridFile(xs, ys)
+        g["u"], g["v"], g["pressure"] = U.ravel(), V.ravel(), P.ravel()
+        g["velocity_magnitude"] = np.sqrt(U**2 + V**2).ravel()
+        # Quirk Q11 (reference base.py:545-549), reproduced on purpose: the splines are built over
+        # (y, x) but the reference asks for dx=1 / dy=1 meaning "d/dx" / "d/dy"; scipy differentiates
+        # along the FIRST / SECOND argument, so the exported array is dv/dy - du/dx, not the vorticity.
+        # The solver's own vorticity (metrics, psi) uses the spectral operators and is unaffected.
+        first = RectBivariateSpline(ys, xs, V)(ys, xs, dx=1)
+        second = RectBivariateSpline(ys, xs, U)(ys, xs, dy=1)
+        g["vorticity"] = (first - second).ravel()
+        g["velocity"] = np.column_stack([U.ravel(), V.ravel(), np.zeros(U.size)])
+        g.field_data.update(Re=np.array([self.params.Re]), N=np.array([self.params.nx]),
+                            solver=np.array([self.params.name]))
+        return g
+
+    def save_vtk(self, filepath):
+        self.to_vtk().save(filepath)

@@ -1,0 +1,168 @@
+"""Sweep farm: one independent trial at a time per GPU, host-side gather.
+
+The reference parallelises over trials only (joblib launcher / Optuna n_jobs / LSF arrays,
+conf/machine/local.yaml:5-9, scripts/hpc_submit.py:103-107); a trajectory itself is sequential.
+Here the workers are the ranks of ``torch.distributed.run`` (one per MI355X, backend nccl = RCCL;
+gloo on CPU for tests).  There is NO collective in the data path: each rank runs its trials on its
+own GPU and only the small result records are gathered (``all_gather_object``).
+"""
+from __future__ import annotations
+
+import math
+import os
+import time
+
+import numpy as np
+
+
+def trial_cost(trial: dict) -> float:
+    """Relative cost model for scheduling: N^3 per step times ~N^2 steps to converge."""
+    n = float(dict(trial).get("N", 32))
+    return n**5
+
+
+def assign_lpt(costs, n_workers: int) -> list:
+    """Longest-processing-time-first: returns worker index per job (deterministic)."""
+    load = [0.0] * n_workers
+    owner = [0] * len(costs)
+    for j in sorted(range(len(costs)), key=lambda q: (-costs[q], q)):
+        w = min(range(n_workers), key=lambda q: (load[q], q))
+        owner[j] = w
+        load[w] += costs[j]
+    return owner
+
+
+class Dist:
+    """Thin view of torch.distributed that also works without it (world size 1)."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self._pg = None
+
+    def init(self, backend: str = None):
+        if self.world > 1 and self._pg is None:
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            kw = {}
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                kw["device_id"] = torch.device(f"cuda:{self.local_rank}")
+            dist.init_process_group(backend, **kw)
+            self._pg = dist
+        return self
+
+    def barrier(self):
+        if self._pg is not None:
+            self._pg.barrier()
+
+    def all_gather_object(self, obj) -> list:
+        if self._pg is None:
+            return [obj]
+        out = [None] * self.world
+        self._pg.all_gather_object(out, obj)
+        return out
+
+    def max_float(self, x: float) -> float:
+        """max over ranks of a host scalar (used for the bench's max-over-ranks time)."""
+        return max(self.all_gather_object(float(x)))
+
+    def close(self):
+        if self._pg is not None:
+            self._pg.destroy_process_group()
+            self._pg = None
+
+
+def run_farm(trials: list, run_trial, dist: Dist, cost=trial_cost) -> list:
+    """Run every trial exactly once; returns the list of result records on every rank, in trial order.
+
+    ``run_trial(trial, index)`` -> JSON-able dict.  Scheduling is static LPT computed identically on all
+    ranks, so no work needs to be communicated."""
+    owner = assign_lpt([cost(t) for t in trials], dist.world)
+    mine = {}
+    for idx, t in enumerate(trials):
+        if owner[idx] == dist.rank:
+            t0 = time.perf_counter()
+            rec = dict(run_trial(t, idx))
+            rec.update(trial_index=idx, rank=dist.rank, trial_seconds=time.perf_counter() - t0)
+            mine[idx] = rec
+    merged = {}
+    for part in dist.all_gather_object(mine):
+        merged.update(part)
+    return [merged[i] for i in range(len(trials))]
+
+
+class TPESampler:
+    """Small tree-structured Parzen estimator for low-dimensional mixed spaces (minimisation).
+
+    Stands in for Optuna's TPE sampler behind ``conf/hydra/sweeper/optuna_corner.yaml`` (Optuna is not
+    installed).  Deterministic for a given seed; every rank holds an identical copy and is told the
+    same gathered results, so no sampler state is communicated."""
+
+    def __init__(self, space: dict, seed: int = 0, n_startup: int = 8, gamma: float = 0.25, n_candidates: int = 24):
+        from utilities.config.compose import Interval
+        self.space, self.rng = dict(space), np.random.default_rng(seed)
+        self.n_startup, self.gamma, self.n_candidates = n_startup, gamma, n_candidates
+        self.Interval = Interval
+        self.trials, self.values = [], []
+
+    def _random(self):
+        out = {}
+        for k, dom in self.space.items():
+            if isinstance(dom, self.Interval):
+                out[k] = float(self.rng.uniform(dom.low, dom.high))
+            else:
+                out[k] = dom[int(self.rng.integers(len(dom)))]
+        return out
+
+    def _score(self, x, group):
+        """log density of x under a Parzen window over `group` (product over dimensions)."""
+        s = 0.0
+        for k, dom in self.space.items():
+            vals = [g[k] for g in group]
+            if isinstance(dom, self.Interval):
+                width = dom.high - dom.low
+                bw = max(width / max(len(vals), 1) ** 0.5 / 2.0, 1e-3 * width)
+                z = (x[k] - np.array(vals)) / bw
+                s += math.log(np.mean(np.exp(-0.5 * z * z)) / bw + 1e-300)
+            else:
+                cnt = sum(1 for v in vals if v == x[k])
+                s += math.log((cnt + 1.0) / (len(vals) + len(dom)))
+        return s
+
+    def ask(self) -> dict:
+        finite = [(t, v) for t, v in zip(self.trials, self.values) if math.isfinite(v)]
+        if len(finite) < self.n_startup:
+            return self._random()
+        finite.sort(key=lambda tv: tv[1])
+        n_good = max(1, int(math.ceil(self.gamma * len(finite))))
+        good, bad = [t for t, _ in finite[:n_good]], [t for t, _ in finite[n_good:]] or [t for t, _ in finite]
+        best, best_s = None, -math.inf
+        for _ in range(self.n_candidates):
+            base = good[int(self.rng.integers(len(good)))]
+            cand = {}
+            for k, dom in self.space.items():
+                if isinstance(dom, self.Interval):
+                    width = dom.high - dom.low
+                    cand[k] = float(np.clip(base[k] + self.rng.normal(0.0, width / 6.0), dom.low, dom.high))
+                else:
+                    cand[k] = base[k] if self.rng.random() < 0.7 else dom[int(self.rng.integers(len(dom)))]
+            sc = self._score(cand, good) - self._score(cand, bad)
+            if sc > best_s:
+                best, best_s = cand, sc
+        return best
+
+    def tell(self, trial: dict, value: float):
+        self.trials.append(dict(trial))
+        self.values.append(float(value) if value is not None else math.inf)
+
+    @property
+    def best(self):
+        if not self.values:
+            return None, math.inf
+        i = int(np.argmin(self.values))
+        return self.trials[i], self.values[i]

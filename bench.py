@@ -184,21 +184,14 @@ def main():
     a = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from utilities.sweep.farm import Dist
+    dist = Dist()
+    rank, world, local = dist.rank, dist.world, dist.local_rank
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    dist.init("nccl")          # RCCL; used for the barrier and the max-over-ranks of the elapsed time only
+    barrier = dist.barrier
 
     import __graft_entry__ as g
     if rank == 0:
@@ -214,10 +207,7 @@ def main():
 
     wall, ev = timed_iterations(s, a.steps, True, barrier)
     wall_so, _ = timed_iterations(s, a.steps, False, barrier)
-    if dist is not None:
-        t = torch.tensor([wall, wall_so], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, wall_so = float(t[0]), float(t[1])
+    wall, wall_so = dist.max_float(wall), dist.max_float(wall_so)
     ctrl = s.d["ctrl"].cpu().numpy()
     assert int(ctrl[0]) == 0, "latch fired during the bench (tolerance is 0: must not happen)"
     rec = s.d["rec"].cpu().numpy()
@@ -254,8 +244,7 @@ def main():
             out["cpu_baseline"] = None
     s.close()
     barrier()
-    if dist is not None:
-        dist.destroy_process_group()
+    dist.close()
     if rank == 0:
         print(json.dumps(out))
 

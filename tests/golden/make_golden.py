@@ -60,6 +60,19 @@ def _install_shims():
             pass
 
         pv.StructuredGrid = StructuredGrid
+
+        def _read(path):
+            """Harness-side stand-in for pyvista.read: decode the .vts with the stdlib reader of
+            this repository and expose the two attributes base.py:1008-1015 uses."""
+            import importlib.util
+            spec = importlib.util.spec_from_file_location(
+                "ldc_vtkio", OUT.parent.parent / "02689-advancednumericalalgorithmp3_amd" / "src" / "solvers" / "vtkio.py")
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            g = mod.read_vts(path)
+            return types.SimpleNamespace(point_data=g["point_data"], points=g["points"])
+
+        pv.read = _read
         sys.modules["pyvista"] = pv
     src = str(REF / "src")
     if src not in sys.path:
@@ -253,6 +266,15 @@ def g7_converged():
          for k, v in s.metrics.__dict__.items()}
     m["wall_time_seconds"] = float(m["wall_time_seconds"])
     ts = {k: list(map(float, v)) if v else [] for k, v in s.time_series.__dict__.items()}
+    # FV comparison through the reference's own compute_validation_errors (CWD = reference root,
+    # because base.py:995-1001 uses relative data/validation paths)
+    import os
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        m["validation_errors"] = s.compute_validation_errors(save_plots=False)
+    finally:
+        os.chdir(cwd)
     (OUT / "g7_converged_N32_Re100.json").write_text(
         json.dumps(dict(metrics=m, time_series_len={k: len(v) for k, v in ts.items()},
                         time_series_head={k: v[:5] for k, v in ts.items()},

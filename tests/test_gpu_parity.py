@@ -6,6 +6,7 @@ between two OpenBLAS kernels on the reference itself is 8e-16); scalars (dt, nor
 <= 1e-10 rel; single residual evaluation <= 1e-11 rel to the field maximum.
 """
 import json
+import math
 
 import numpy as np
 import pytest
@@ -186,6 +187,12 @@ def test_solve_converges_like_reference(golden_dir):
                 "omega_center", "omega_max", "psi_BR", "psi_BL", "u_momentum_residual", "continuity_residual"):
         assert getattr(m, key) == pytest.approx(meta[key], rel=1e-7, abs=1e-10), key
     assert len(s.time_series.rel_iter_residual) == 1000
+    # the FV comparison, through the reference's own compute_validation_errors in the fixture
+    errs = s.compute_validation_errors()
+    for key, ref in meta["validation_errors"].items():
+        assert errs[key] == pytest.approx(ref, rel=1e-8), key
+    g_err = s.ghia_error()
+    assert 0 < g_err["u_rms"] < 0.02 and 0 < g_err["v_rms"] < 0.02
     # a second solve() on the converged state stops right after the warm-up
     s.solve(max_iter=50)
     assert s.metrics.iterations <= 12
@@ -200,3 +207,31 @@ def test_max_iterations_and_nan_guard():
     d = make(32, 1000.0, nan_guard=True, check_every=512)
     d.solve(max_iter=4000)
     assert not d.metrics.converged and d.metrics.iterations < 4000
+
+
+def test_launcher_single_run_and_sweep(tmp_path, monkeypatch):
+    """main.py: one run (the literal `solver=spectral` alias) and a 2x2 grid sweep, results gathered."""
+    import importlib.util
+    import json as _json
+    from conftest import PKG
+    spec = importlib.util.spec_from_file_location("ldc_main", PKG / "main.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.chdir(tmp_path)
+    obj = mod.main(["solver=spectral", "N=16", "Re=100", "max_iterations=400"])
+    runs = sorted(tmp_path.glob("hydra_outputs/multirun/*/*/0/results.json"))
+    assert len(runs) == 1
+    rec = _json.loads(runs[0].read_text())
+    assert rec["run_name"] == "spectral_N17" and rec["metrics"]["iterations"] == 400
+    assert rec["params"]["nx"] == 16 and rec["params"]["method"] == "Spectral-AC"
+    assert set(rec["validation_errors"]) == {"u_L2_error", "v_L2_error"}
+    assert obj == pytest.approx(math.hypot(rec["validation_errors"]["u_L2_error"], rec["validation_errors"]["v_L2_error"]))
+    assert "ghia" in rec and (runs[0].parent / "solution.vts").exists()
+    from solvers.vtkio import read_vts
+    g = read_vts(runs[0].parent / "solution.vts")
+    assert g["extent"] == (0, 16, 0, 16, 0, 0) and set(g["point_data"]) >= {"u", "v", "pressure", "vorticity", "velocity"}
+    mod.main(["-m", "N=16,20", "Re=100,400", "max_iterations=60"])
+    sweeps = sorted(tmp_path.glob("hydra_outputs/multirun/*/*/sweep_results.json"))
+    recs = _json.loads(sweeps[-1].read_text())
+    assert [(r["N"], r["Re"]) for r in recs] == [(16, 100), (16, 400), (20, 100), (20, 400)]
+    assert all(r["metrics"]["iterations"] == 60 for r in recs)
