@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Converged solves with the reference's stopping rule (rel. change per step < 1e-6) on the GPU:
+iteration counts, wall time, Ghia centreline error (SURVEY 8d Metric 2), Botella table, FV L2 errors.
+
+    python tools/ghia_report.py --cases 64:100,64:400,64:1000,128:1000,256:1000 --out gpurun_out/ghia.json
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (str(ROOT), str(ROOT / "02689-advancednumericalalgorithmp3_amd" / "src")):
+    sys.path.insert(0, p)
+import __graft_entry__ as g  # noqa: E402
+
+g.build()
+from solvers.spectral.sg import SGSolver  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", default="64:100,64:400,64:1000")
+ap.add_argument("--max-iter", type=int, default=4_000_000)
+ap.add_argument("--out", default="gpurun_out/ghia.json")
+a = ap.parse_args()
+out = []
+for case in a.cases.split(","):
+    N, Re = (int(x) for x in case.split(":"))
+    s = SGSolver(name="spectral", Re=float(Re), nx=N, ny=N, basis_type="chebyshev", CFL=1.5, beta_squared=5.0,
+                 corner_treatment="smoothing", corner_smoothing=0.15, tolerance=1e-6, max_iterations=a.max_iter,
+                 check_every=4096, graph_iters=32)
+    t0 = time.perf_counter()
+    s.solve()
+    m = s.metrics
+    rec = dict(N=N, Re=Re, iterations=m.iterations, converged=m.converged, wall_time_seconds=m.wall_time_seconds,
+               steps_per_second=m.iterations / m.wall_time_seconds, total_seconds=time.perf_counter() - t0,
+               final_residual=m.final_residual, psi_min=m.psi_min, psi_min_x=m.psi_min_x, psi_min_y=m.psi_min_y,
+               omega_center=m.omega_center, psi_BR=m.psi_BR, psi_BL=m.psi_BL, E=m.final_energy, Z=m.final_enstrophy,
+               P=m.final_palinstrophy, u_residual=m.u_momentum_residual, ghia=s.ghia_error(),
+               fv=s.compute_validation_errors(), botella=s.validation_table())
+    out.append(rec)
+    print(json.dumps({k: v for k, v in rec.items() if k != "botella"}), flush=True)
+    Path(a.out).parent.mkdir(parents=True, exist_ok=True)
+    Path(a.out).write_text(json.dumps(out, indent=1))
+    s.close()
