@@ -854,6 +854,36 @@ __global__ __launch_bounds__(kThreads) void palin_kernel(const PalinArgs a) {
 // ---------------------------------------------------------------------------------------
 // finalize: one work-group folds the per-block partials in a fixed order
 // ---------------------------------------------------------------------------------------
+// E, Z, P of the current state in one go: folds the Z/P partial slabs (written by an ungated
+// post + palin pair just before, parity slab selected by ctrl[STEP] exactly as they do) and
+// integrates the kinetic energy directly.  One work-group, fixed order.
+__global__ __launch_bounds__(kThreads) void quantities_parity_kernel(const double* U, const double* V, const double* wx,
+                                                                    const double* wy, int M, int LD, const double* partZ0,
+                                                                    const double* partP0, long long stride, int nblk,
+                                                                    const int* ctrl, double* out) {
+  __shared__ double sm[3 * kThreads];
+  const int step = ctrl[LDC_CTRL_STEP];
+  const size_t off = (size_t)((step > 0 ? step - 1 : 0) & 1) * (size_t)stride;
+  const double *partZ = partZ0 + off, *partP = partP0 + off;
+  const int t = threadIdx.x;
+  double e = 0.0, z = 0.0, p = 0.0;
+  for (int q = t; q < M * M; q += kThreads) {
+    const int i = q / M, j = q % M;
+    const double u = U[(size_t)i * LD + j], v = V[(size_t)i * LD + j];
+    e += wx[i] * wy[j] * (u * u + v * v);
+  }
+  for (int r = t; r < nblk; r += kThreads) { z += partZ[(size_t)r * LDC_NPART]; p += partP[(size_t)r * LDC_NPART]; }
+  sm[t] = e; sm[kThreads + t] = z; sm[2 * kThreads + t] = p;
+  __syncthreads();
+  for (int h = kThreads / 2; h > 0; h >>= 1) {
+    if (t < h) {
+      sm[t] += sm[t + h]; sm[kThreads + t] += sm[kThreads + t + h]; sm[2 * kThreads + t] += sm[2 * kThreads + t + h];
+    }
+    __syncthreads();
+  }
+  if (t == 0) { out[0] = 0.5 * sm[0]; out[1] = 0.5 * sm[kThreads]; out[2] = 0.5 * sm[2 * kThreads]; }
+}
+
 // dt of the very first iteration: max |u|, max |v| over the whole padded arrays
 __global__ __launch_bounds__(kThreads) void prime_kernel(const double* U, const double* V, int n, FinalArgs a) {
   __shared__ double sm[2 * kWaves];
@@ -1040,7 +1070,12 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
                        {p.UA, p.UAT, p.VA, p.VAT}, {p.U, p.UT, p.V, p.VT}};
   a.Uin = in[k][0]; a.UinT = in[k][1]; a.Vin = in[k][2]; a.VinT = in[k][3];
   a.Uout = out[k][0]; a.UoutT = out[k][1]; a.Vout = out[k][2]; a.VoutT = out[k][3];
-  a.Pout = (k == 3) ? p.P : nullptr;   // SG never consumes the stage pressures (quirk Q1)
+  if (p.stage_pressure) {
+    double* pout[4] = {p.PA, p.PB, p.PA, p.P};   // FSG smoother: p_stage is consumed by the next stage
+    a.Pout = pout[k];
+  } else {
+    a.Pout = (k == 3) ? p.P : nullptr;           // SG never consumes the stage pressures (quirk Q1)
+  }
   return a;
 }
 
@@ -1059,6 +1094,10 @@ int launch_stage_variant(const StageArgs& a, int nt, hipStream_t st) {
 
 int launch_stage(ldc_solver* s, int k, hipStream_t st) {
   const StageArgs a = make_stage_args(s, k);
+  if (s->p.stage_pressure) {   // every stage differentiates its own input pressure (T1T/T2T are fresh)
+    if (k < 3) return launch_stage_variant<true, false, false>(a, s->nt, st);
+    return launch_stage_variant<true, true, false>(a, s->nt, st);
+  }
   if (k == 0) return launch_stage_variant<true, false, false>(a, s->nt, st);
   if (k < 3) return launch_stage_variant<false, false, false>(a, s->nt, st);
   return launch_stage_variant<false, true, false>(a, s->nt, st);
@@ -1123,8 +1162,14 @@ int launch_finalize(const ldc_solver* s, int with_diag, int do_critical, hipStre
 // next iteration's post launch or by the flush at the end of ldc_solver_enqueue
 int launch_iteration(ldc_solver* s, int with_diag, hipStream_t st) {
   int e;
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < 4; ++k) {
     if ((e = launch_stage(s, k, st)) != 0) return e;
+    if (s->p.stage_pressure && k < 3) {
+      // transforms of the stage pressure just produced (PA, PB, PA) for the next stage
+      const double* pk = (k == 1) ? s->p.PB : s->p.PA;
+      if ((e = launch_post(s, pk, 0, 0, 0, st)) != 0) return e;
+    }
+  }
   if ((e = launch_post(s, s->p.P, with_diag, 1, with_diag, st)) != 0) return e;
   if (with_diag && (e = launch_palin(s, 1, st)) != 0) return e;
   return 0;
@@ -1178,7 +1223,8 @@ int ldc_solver_create(const ldc_problem* d, ldc_solver** out) {
   if (d->M < 4 || d->T < 1 || d->T != (d->M - 1 + 15) / 16) return LDC_E_ARG;
   if (d->LD % 16 != 0 || d->LD < 16 * d->T + 16 || d->LD < d->M) return LDC_E_ARG;
   if (d->tail != ((16 * d->T == d->M - 1) ? 1 : 0)) return LDC_E_ARG;
-  if (d->rec_cap < 1 || d->stage_pressure != 0) return LDC_E_ARG;
+  if (d->rec_cap < 1 || (d->stage_pressure != 0 && d->stage_pressure != 1)) return LDC_E_ARG;
+  if (d->stage_pressure && (!d->PA || !d->PB)) return LDC_E_ARG;
   const void* req[] = {d->Dx, d->D2x, d->Dy, d->D2y, d->IxF, d->GxF, d->IyF, d->GyF, d->wx, d->wy, d->ulid,
                        d->DxL, d->D2xL, d->DyL, d->D2yL,
                        d->U, d->UT, d->V, d->VT, d->P, d->UA, d->UAT, d->VA, d->VAT, d->UB, d->UBT, d->VB,
@@ -1238,6 +1284,19 @@ int ldc_diagnostics(ldc_solver* s, void* stream) {
   int e = launch_post(s, s->p.P, 1, 0, 0, as_stream(stream));
   if (e) return e;
   return launch_palin(s, 0, as_stream(stream));
+}
+
+int ldc_global_quantities(ldc_solver* s, double* out3, void* stream) {
+  if (!s || !out3) return LDC_E_ARG;
+  hipStream_t st = as_stream(stream);
+  int e = launch_post(s, s->p.P, 1, 0, 0, st);
+  if (e) return e;
+  if ((e = launch_palin(s, 0, st)) != 0) return e;
+  const ldc_problem& p = s->p;
+  hipLaunchKernelGGL(quantities_parity_kernel, dim3(1), dim3(kThreads), 0, st, p.U, p.V, p.wx, p.wy, p.M, p.LD,
+                     p.partials + p.partials_stride, p.partials + 3 * p.partials_stride, (long long)p.partials_stride,
+                     s->nt + s->n_edge_blocks, p.ctrl, out3);
+  return (int)hipGetLastError();
 }
 
 int ldc_finalize(ldc_solver* s, int with_diag, void* stream) {

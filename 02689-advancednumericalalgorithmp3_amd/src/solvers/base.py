@@ -81,7 +81,9 @@ class LidDrivenCavitySolver(ABC):
         log.info("Solver finished in %.2f seconds.", wall)
 
         hist = np.concatenate(blocks, axis=0) if blocks else np.zeros((0, 8))
-        self._store_results(hist, total, done == 1, wall)
+        self.history = hist
+        # the reference keeps history only after the first 10 iterations (base.py:264)
+        self._store_results(hist[WARMUP_ITERATIONS:], total, done == 1, wall)
 
     @staticmethod
     def _downsample(values: list, limit: int):
@@ -90,14 +92,13 @@ class LidDrivenCavitySolver(ABC):
         pick = np.linspace(0, len(values) - 1, limit, dtype=int)     # base.py:141
         return [values[i] for i in pick]
 
-    def _store_results(self, hist: np.ndarray, iterations: int, converged: bool, wall: float,
-                       max_timeseries_points: int = 1000):
-        """hist holds one row per iteration (all of them); the reference keeps i >= 10 only."""
-        kept = hist[WARMUP_ITERATIONS:]
-        with_diag = bool(getattr(self.params, "diagnostics", True))
+    def _store_results(self, kept: np.ndarray, iterations: int, converged: bool, wall: float,
+                       max_timeseries_points: int = 1000, with_diag: bool = None):
+        """`kept`: one row per recorded iteration (columns REL..DT)."""
+        if with_diag is None:
+            with_diag = bool(getattr(self.params, "diagnostics", True))
         col = lambda c: kept[:, c].tolist()                           # noqa: E731
         ds = lambda v: self._downsample(v, max_timeseries_points)     # noqa: E731
-        self.history = hist
         self._finalize_fields()
         self.time_series = TimeSeries(
             rel_iter_residual=ds(col(REL)), u_residual=ds(col(RU)), v_residual=ds(col(RV)),

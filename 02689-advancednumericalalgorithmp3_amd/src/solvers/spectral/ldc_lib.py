@@ -71,6 +71,7 @@ def lib() -> C.CDLL:
     L.ldc_pressure_transform.argtypes = [_dp, C.c_int, _dp]
     L.ldc_diagnostics.argtypes = [_dp, _dp]
     L.ldc_finalize.argtypes = [_dp, C.c_int, _dp]
+    L.ldc_global_quantities.argtypes = [_dp, _dp, _dp]
     L.ldc_prime.argtypes = [_dp, _dp]
     L.ldc_solver_enqueue.argtypes = [_dp, C.c_int, C.c_int, _dp]
     L.ldc_residual_debug.argtypes = [_dp, C.c_int, C.POINTER(_dp), _dp]
@@ -90,7 +91,7 @@ def lib() -> C.CDLL:
 # every symbol include/ldc_hip.h declares (tests check the .so exports all of them)
 EXPORTS = (
     "ldc_version", "ldc_error_string", "ldc_device_check", "ldc_solver_create", "ldc_solver_destroy",
-    "ldc_stage", "ldc_pressure_transform", "ldc_diagnostics", "ldc_finalize", "ldc_prime",
+    "ldc_stage", "ldc_pressure_transform", "ldc_diagnostics", "ldc_finalize", "ldc_prime", "ldc_global_quantities",
     "ldc_solver_enqueue", "ldc_solver_set_graph_iters", "ldc_residual_debug", "ldc_gemm_nt",
     "ldc_poisson_fastdiag", "ldc_vortex_extrema", "ldc_mfma_selftest", "ldc_mfma_peak", "ldc_debug_ablate",
 )

@@ -86,6 +86,11 @@ class SGSolver(LidDrivenCavitySolver):
         self._handle = None
         self._handle_tol = None
         self._eig = None
+        # loop flavour: SG (reference sg.py/base.py) unless a subclass switches to the FSG smoother
+        self._stage_pressure = 0          # 1: every RK stage differentiates its own stage pressure
+        self._warmup = 10                 # iterations without convergence test (base.py:264, 283)
+        self._nan_exit = None             # None: follow params.nan_guard
+        self._edge_fix_pending = False
         self.reset_state()
 
     # ------------------------------------------------------------------ host-side setup
@@ -180,12 +185,39 @@ class SGSolver(LidDrivenCavitySolver):
             full = np.zeros((M, M))
             full[1:-1, 1:-1] = np.asarray(p, float).reshape(M - 2, M - 2)
             self._upload_full("P", full)
-        # stage buffers carry the same boundary row/column (never rewritten when `tail`)
         for src, dsts in (("U", ("UA", "UB")), ("UT", ("UAT", "UBT")), ("V", ("VA", "VB")),
                           ("VT", ("VAT", "VBT")), ("P", ("PA", "PB"))):
             for dn in dsts:
                 self.d[dn].copy_(self.d[src])
+        if self.tail:
+            # Index M-1 is never rewritten by the tiles.  The RK stage buffers must carry the
+            # boundary VALUES there (the reference re-imposes them after every stage); phi^n itself
+            # keeps whatever was uploaded for the first iteration and is corrected right after it.
+            self._write_boundary_edges(("UA", "UAT", "VA", "VAT"))
+            self._write_boundary_edges(("UB", "UBT", "VB", "VBT"))
+            self._edge_fix_pending = True
         self._primed = False
+
+    def _write_boundary_edges(self, names):
+        """Boundary values on the row/column of index M-1 of (U, UT, V, VT)-like arrays."""
+        m1, M = self.M - 1, self.M
+        U, UT, V, VT = (self.d[n] for n in names)
+        lid = self.d["ulid"][:M]
+        U[m1, :M] = 0.0; U[:M, m1] = lid          # east wall, then the lid (lid wins the corner)
+        UT[:M, m1] = 0.0; UT[m1, :M] = lid
+        V[m1, :M] = 0.0; V[:M, m1] = 0.0
+        VT[:M, m1] = 0.0; VT[m1, :M] = 0.0
+
+    def set_state_device(self, u, v, p_inner):
+        """Same as set_state for torch tensors already on the device ((M,M), (M,M), (M-2,M-2))."""
+        M = self.M
+        for name, tname, a in (("U", "UT", u), ("V", "VT", v)):
+            self.d[name].zero_(); self.d[tname].zero_()
+            self.d[name][:M, :M] = a
+            self.d[tname][:M, :M] = a.t()
+        self.d["P"].zero_()
+        self.d["P"][1: M - 1, 1: M - 1] = p_inner
+        self.set_state()
 
     def reset_state(self):
         """Fluid at rest with the regularised lid (reference sg.py:76-98)."""
@@ -203,7 +235,9 @@ class SGSolver(LidDrivenCavitySolver):
         pr.M, pr.LD, pr.T, pr.tail = self.M, self.LD, self.T, self.tail
         pr.nu, pr.beta2, pr.cfl = 1.0 / p.Re, p.beta_squared, p.CFL
         pr.hx_min, pr.hy_min, pr.lid_speed, pr.tol = self.dx_min, self.dy_min, p.lid_velocity, tol
-        pr.warmup, pr.nan_guard, pr.stage_pressure, pr.rec_cap = 10, int(bool(p.nan_guard)), 0, self.rec_cap
+        nan_exit = bool(p.nan_guard) if self._nan_exit is None else bool(self._nan_exit)
+        pr.warmup, pr.nan_guard, pr.stage_pressure, pr.rec_cap = (
+            int(self._warmup), int(nan_exit), int(self._stage_pressure), self.rec_cap)
         for name, _ in L.Problem._fields_:
             if name in self.d and name != "partials_stride":
                 setattr(pr, name, self.d[name].data_ptr())
@@ -211,8 +245,10 @@ class SGSolver(LidDrivenCavitySolver):
         return pr
 
     def _ensure_handle(self, tol: float):
-        if self._handle is not None and self._handle_tol == tol:
+        key = (tol, self._stage_pressure, self._warmup, self._nan_exit)
+        if self._handle is not None and self._handle_key == key:
             return
+        self._handle_key = key
         self.close()
         h = C.c_void_p()
         pr = self._problem(tol)
@@ -251,6 +287,13 @@ class SGSolver(LidDrivenCavitySolver):
         ctrl0 = self.d["ctrl"].cpu().numpy()
         start = int(ctrl0[L.CTRL_ITER])
         n_iters = min(int(n_iters), self.rec_cap)
+        if self._edge_fix_pending and n_iters > 1:
+            # first iteration after an upload: afterwards phi^n carries its boundary values
+            rows1, done1, end1 = self._advance(1)
+            if done1 or n_iters == 1:
+                return rows1, done1, end1
+            rows2, done2, end2 = self._advance(n_iters - 1)
+            return np.concatenate([rows1, rows2], axis=0), done2, end2
         with torch.cuda.device(self.device):
             L.check(L.lib().ldc_solver_enqueue(self._handle, n_iters, int(bool(self.params.diagnostics)),
                                                L.stream_ptr()), "ldc_solver_enqueue")
@@ -259,6 +302,9 @@ class SGSolver(LidDrivenCavitySolver):
         end, done = int(ctrl[L.CTRL_ITER]), int(ctrl[L.CTRL_DONE])
         ring = self.d["rec"].cpu().numpy()
         rows = ring[np.arange(start, end) % self.rec_cap]
+        if self._edge_fix_pending and end > start:
+            self._write_boundary_edges(("U", "UT", "V", "VT"))
+            self._edge_fix_pending = False
         return rows, done, end
 
     def step(self):
@@ -324,6 +370,16 @@ class SGSolver(LidDrivenCavitySolver):
             a = outs[k][:M, :M].cpu().numpy()
             res[key] = a[1:-1, 1:-1].ravel().copy() if key == "R_p" else a.ravel()
         return res
+
+    def global_quantities(self) -> dict:
+        """E, Z, P of the current state, computed on the device (reference sg.py:495-550)."""
+        import torch
+        self._ensure_handle(self.params.tolerance if self._handle_tol is None else self._handle_tol)
+        out = self.d["ext_val"]
+        L.check(L.lib().ldc_global_quantities(self._handle, out.data_ptr(), L.stream_ptr()), "ldc_global_quantities")
+        torch.cuda.synchronize(self.device)
+        e, z, p = out[:3].cpu().numpy()
+        return {"E": float(e), "Z": float(z), "P": float(p)}
 
     # ---- vorticity / stream function / vortices (reference sg.py:510-743) --------------------
     def _compute_vorticity(self) -> np.ndarray:

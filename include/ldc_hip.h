@@ -83,7 +83,7 @@ typedef struct ldc_problem {
   double tol;         /* convergence tolerance on LDC_REC_REL                          */
   int32_t warmup;     /* iterations without convergence test (10, base.py:264,283)     */
   int32_t nan_guard;  /* latch on a non-finite change norm (quirk Q6)                  */
-  int32_t stage_pressure; /* 0: SG (quirk Q1, grad p^n in all stages); 1: FSG smoother */
+  int32_t stage_pressure; /* 0: SG (quirk Q1, grad p^n in all stages); 1: FSG smoother (multigrid/fsg.py:880) */
   int32_t rec_cap;    /* capacity of `rec` in records                                  */
   /* operators, read-only: row-major LD x LD, zero padded                               */
   const double *Dx, *D2x, *Dy, *D2y;   /* sg.py:188-193                                */
@@ -131,6 +131,10 @@ int ldc_pressure_transform(ldc_solver *s, int which, void *stream);
 /* vorticity, enstrophy and palinstrophy partial sums of the current state               */
 /* replaces sg.py:510-550 (called per iteration at base.py:274-276)                      */
 int ldc_diagnostics(ldc_solver *s, void *stream);
+/* E, Z, P of the current state into out3[0..2] (device pointer); one-off form of the        */
+/* per-iteration diagnostics, sg.py:495-550 (used where the reference calls them once,       */
+/* e.g. fsg.py:120-123)                                                                      */
+int ldc_global_quantities(ldc_solver *s, double *out3, void *stream);
 /* reduces the partial sums: change norms, residual norms, E/Z/P, next dt, latch, record */
 /* replaces sg.py:387-408, base.py:250-258, :283-286, sg.py:463-473                      */
 int ldc_finalize(ldc_solver *s, int with_diagnostics, void *stream);

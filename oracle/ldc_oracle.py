@@ -362,3 +362,92 @@ def ghia_centerline_error(x, y, U, V, ghia_u_xy, ghia_v_xy):
     return dict(u_rms=float(np.sqrt(np.mean(eu**2))), v_rms=float(np.sqrt(np.mean(ev**2))),
                 u_rel=float(np.linalg.norm(eu) / np.linalg.norm(ug)),
                 v_rel=float(np.linalg.norm(ev) / np.linalg.norm(vg)))
+
+
+# --------------------------------------------------------------------------- FSG (a20)
+def fft_prolongation_matrix(nc: int, nf: int) -> np.ndarray:
+    """(nf, nc) matrix of the reference's ``FFTProlongation.prolongate_1d``
+    (operators/transfer_operators.py:209-255), restated in closed form.
+
+    The reference halves the end samples, applies SciPy's un-normalised DCT-I (which already
+    weights the ends by 1/2 relative to the interior: y_k = x_0 + (-1)^k x_N + 2 sum x_n cos),
+    divides by N_c, halves the end coefficients and sums c_k cos(k pi i / N_f).  The double end
+    weighting makes it NOT an interpolation (quirk Q10); it is reproduced as is.  It is linear,
+    so the matrix is the operator applied to unit vectors."""
+    if nc == nf:
+        return np.eye(nc)
+    if nc > nf:
+        raise ValueError(f"Prolongation requires n_coarse ({nc}) <= n_fine ({nf})")
+    Nc, Nf = nc - 1, nf - 1
+    k = np.arange(nc)
+    j = np.arange(nc)
+    dct1 = 2.0 * np.cos(np.pi * np.outer(k, j) / Nc)      # interior columns
+    dct1[:, 0] = 1.0
+    dct1[:, -1] = (-1.0) ** k
+    w_in = np.ones(nc); w_in[[0, -1]] = 0.5                # "u_weighted[0] /= 2 ..."
+    w_c = np.ones(nc); w_c[[0, -1]] = 0.5                  # "coeffs[0] /= 2 ..."
+    coeff = (w_c[:, None] * dct1 * w_in[None, :]) / Nc     # coefficients of each unit vector
+    ev = np.cos(np.pi * np.outer(np.arange(nf), k) / Nf)   # T_k at the fine angles
+    return ev @ coeff
+
+
+def fsg_orders(n_fine: int, n_levels: int, coarsest_n: int = 12) -> list:
+    """Polynomial orders coarse -> fine (multigrid/fsg.py:517-531)."""
+    orders, n = [], n_fine
+    for _ in range(n_levels):
+        orders.append(n)
+        if n // 2 < coarsest_n:
+            break
+        n //= 2
+    return orders[::-1]
+
+
+def fsg_prolongate(coarse: "OracleSG", fine: "OracleSG", lid_velocity: float):
+    """multigrid/fsg.py:551-614 including quirk Q2: the boundary re-imposition uses [ix, iy]
+    arrays as if they were [iy, ix], so the EAST wall gets the (scalar) lid speed and the lid
+    row is zeroed; the caller's initialize_lid then restores the lid column."""
+    Pf = fft_prolongation_matrix(coarse.M, fine.M)
+    Pi = fft_prolongation_matrix(coarse.Mi, fine.Mi)
+    u = Pf @ coarse.u @ Pf.T
+    v = Pf @ coarse.v @ Pf.T
+    u[0, :] = 0.0; v[0, :] = 0.0
+    u[-1, :] = lid_velocity; v[-1, :] = 0.0
+    u[:, 0] = 0.0; v[:, 0] = 0.0
+    u[:, -1] = 0.0; v[:, -1] = 0.0
+    fine.u, fine.v = u, v
+    fine.p = Pi @ coarse.p @ Pi.T
+
+
+def oracle_fsg(N, Re, *, tolerance=1e-6, max_iterations=500000, n_levels=2, coarse_tolerance_factor=1.0,
+               **kw):
+    """``solve_fsg`` (multigrid/fsg.py:1053-1221): coarse -> fine, the smoother differentiates the
+    STAGE pressure, no warm-up, NaN/Inf exit.  Returns (finest level, total iterations, converged)."""
+    orders = fsg_orders(N, n_levels)
+    U = kw.get("lid_velocity", 1.0)
+    levels = [OracleSG(n, Re, stage_pressure=True, **kw) for n in orders]
+    total, converged, diverged = 0, False, False
+    for idx, lvl in enumerate(levels):
+        tol = tolerance * coarse_tolerance_factor ** (len(levels) - 1 - idx)
+        if idx == 0:
+            lvl.u[:] = 0.0; lvl.v[:] = 0.0; lvl.p[:] = 0.0
+        else:
+            fsg_prolongate(levels[idx - 1], lvl, U)
+        lvl.u[:, -1] = lvl.u_lid                       # initialize_lid (:950-954)
+        lvl.v[:, -1] = 0.0
+        converged = False
+        for _ in range(max_iterations):
+            up, vp = lvl.u.copy(), lvl.v.copy()
+            lvl.step()
+            ur = np.linalg.norm(lvl.u - up) / (np.linalg.norm(up) + 1e-12)
+            vr = np.linalg.norm(lvl.v - vp) / (np.linalg.norm(vp) + 1e-12)
+            total += 1
+            mr = max(ur, vr)
+            if mr < tol:
+                converged = True
+                break
+            if not np.isfinite(mr):
+                diverged = True
+                break
+        if diverged:
+            break
+    return levels[-1], total, bool(converged and not diverged)

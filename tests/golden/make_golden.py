@@ -303,9 +303,62 @@ def g11_interp():
     np.savez_compressed(OUT / "g11_interp.npz", **out)
 
 
+def make_fsg(N, Re, **kw):
+    _install_shims()
+    fsg = importlib.import_module("solvers.spectral.fsg")
+    args = dict(
+        name="spectral_fsg", Re=Re, lid_velocity=1.0, Lx=1.0, Ly=1.0, nx=N, ny=N,
+        tolerance=1e-6, max_iterations=500000, basis_type="chebyshev", CFL=1.5,
+        beta_squared=5.0, corner_treatment="smoothing", corner_smoothing=0.15,
+        multigrid="fsg", n_levels=2, coarse_tolerance_factor=1.0,
+        prolongation_method="fft", restriction_method="fft",
+    )
+    args.update(kw)
+    with kron_guard():
+        return fsg.FSGSolver(**args)
+
+
+def g8_fsg(full=False):
+    """FSG path (a20): prolongation operator (quirk Q10), capped two-level runs (quirk Q2), the
+    single-level fallback of build_hierarchy, and one fully converged FSG solve."""
+    _install_shims()
+    tr = importlib.import_module("solvers.spectral.operators.transfer_operators")
+    rng = np.random.default_rng(8)
+    out = {}
+    pro = tr.FFTProlongation()
+    for nc, nf in ((17, 33), (15, 31), (13, 25), (9, 19)):
+        f = rng.standard_normal((nc, nc))
+        out[f"pro_in_{nc}_{nf}"] = f
+        out[f"pro_out_{nc}_{nf}"] = pro.prolongate_2d(f, (nf, nf))
+        out[f"pro_mat_{nc}_{nf}"] = np.stack([pro.prolongate_1d(e, nf) for e in np.eye(nc)], axis=1)
+    np.savez_compressed(OUT / "g8_prolongation.npz", **out)
+
+    runs = {}
+    cases = [("cap300_N32_Re100", 32, 100.0, dict(max_iterations=300)),
+             ("cap200_N24_Re400", 24, 400.0, dict(max_iterations=200, corner_smoothing=0.1)),
+             ("single_N20_Re100", 20, 100.0, dict(max_iterations=250)),
+             ("cap150_N48_Re1000_saad", 48, 1000.0, dict(max_iterations=150, corner_treatment="saad")),
+             ("lvl3_N48_Re100", 48, 100.0, dict(max_iterations=120, n_levels=3, coarse_tolerance_factor=10.0))]
+    if full:
+        cases.append(("full_N32_Re100", 32, 100.0, dict()))
+    meta = {}
+    for name, N, Re, kw in cases:
+        t0 = time.time()
+        with kron_guard():
+            s = make_fsg(N, Re, **kw)
+            s.solve()
+        runs[f"{name}_u"], runs[f"{name}_v"], runs[f"{name}_p"] = s.arrays.u.copy(), s.arrays.v.copy(), s.arrays.p.copy()
+        m = {k: (v.item() if isinstance(v, np.generic) else v) for k, v in s.metrics.__dict__.items()}
+        ts = {k: (list(map(float, v)) if v else []) for k, v in s.time_series.__dict__.items()}
+        meta[name] = dict(N=N, Re=Re, kw=kw, metrics=m, time_series=ts)
+        print(f"  fsg {name}: {m['iterations']} its converged={m['converged']} {time.time() - t0:.1f}s")
+    np.savez_compressed(OUT / "g8_fsg_runs.npz", **runs)
+    (OUT / "g8_fsg_runs.json").write_text(json.dumps(meta, indent=1))
+
+
 GROUPS = {
     "G1": g1_operators, "G2": g2_lid, "G3": g3_single_stage, "G4": g4_trajectories,
-    "G4b": g4b_variants, "G7": g7_converged, "G11": g11_interp,
+    "G4b": g4b_variants, "G7": g7_converged, "G11": g11_interp, "G8": g8_fsg,
 }
 
 
@@ -318,7 +371,7 @@ def main():
     for g in todo:
         t0 = time.time()
         print(f"[{g}]")
-        if g == "G4":
+        if g in ("G4", "G8"):
             GROUPS[g](full=a.full)
         else:
             GROUPS[g]()

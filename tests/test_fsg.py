@@ -1,0 +1,126 @@
+"""FSG path: prolongation operator, hierarchy, the coarse->fine driver.
+CPU part pins the oracle to reference fixtures (tests/golden/g8_*); GPU part checks the HIP path."""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import ldc_oracle as orc
+from solvers.spectral.fsg import hierarchy_orders
+from solvers.spectral.operators.transfer_operators import prolongation_matrix
+
+
+@pytest.fixture(scope="module")
+def runs(golden_dir):
+    return np.load(golden_dir / "g8_fsg_runs.npz"), json.loads((golden_dir / "g8_fsg_runs.json").read_text())
+
+
+def test_hierarchy_orders_follow_the_reference():
+    assert hierarchy_orders(32, 2) == [16, 32] and hierarchy_orders(256, 2) == [128, 256]
+    assert hierarchy_orders(20, 2) == [20]                  # 10 < coarsest_n = 12: single level
+    assert hierarchy_orders(30, 2) == [15, 30] and hierarchy_orders(48, 3) == [12, 24, 48]
+    assert hierarchy_orders(64, 3) == [16, 32, 64] and orc.fsg_orders(64, 3) == [16, 32, 64]
+
+
+@pytest.mark.parametrize("nc,nf", [(17, 33), (15, 31), (13, 25), (9, 19)])
+def test_prolongation_matrix_matches_reference(golden_dir, nc, nf):
+    g = np.load(golden_dir / "g8_prolongation.npz")
+    for P in (prolongation_matrix("fft", nc, nf), orc.fft_prolongation_matrix(nc, nf)):
+        assert np.max(np.abs(P - g[f"pro_mat_{nc}_{nf}"])) < 5e-15
+        got = P @ g[f"pro_in_{nc}_{nf}"] @ P.T
+        assert np.max(np.abs(got - g[f"pro_out_{nc}_{nf}"])) < 5e-14
+    # quirk Q10: a constant is NOT reproduced (end weights applied twice) -- kept on purpose
+    assert abs((prolongation_matrix("fft", nc, nf) @ np.ones(nc))[0] - 0.5) < 1e-12
+    assert np.max(np.abs(prolongation_matrix("polynomial", nc, nf) @ np.ones(nc) - 1.0)) < 1e-12
+    with pytest.raises(ValueError):
+        prolongation_matrix("spline", nc, nf)
+
+
+CAPPED = ["cap300_N32_Re100", "cap200_N24_Re400", "single_N20_Re100", "cap150_N48_Re1000_saad", "lvl3_N48_Re100"]
+
+
+@pytest.mark.parametrize("name", CAPPED)
+def test_oracle_fsg_capped_runs(runs, name):
+    """Iteration-capped FSG runs: every level hits the cap, so the final fields expose the smoother
+    (stage pressure), the prolongation (Q10) and its boundary re-imposition (Q2).  The reference's
+    Numba kernels are fastmath; tolerance 1e-10."""
+    g, meta = runs
+    c = meta[name]
+    kw = {k: v for k, v in c["kw"].items() if k in ("corner_smoothing", "corner_treatment")}
+    lvl, total, conv = orc.oracle_fsg(c["N"], c["Re"], max_iterations=c["kw"]["max_iterations"],
+                                      n_levels=c["kw"].get("n_levels", 2),
+                                      coarse_tolerance_factor=c["kw"].get("coarse_tolerance_factor", 1.0), **kw)
+    assert total == c["metrics"]["iterations"] and conv == c["metrics"]["converged"]
+    assert np.max(np.abs(lvl.u.ravel() - g[f"{name}_u"])) < 1e-10
+    assert np.max(np.abs(lvl.v.ravel() - g[f"{name}_v"])) < 1e-10
+    assert np.max(np.abs(lvl.p.ravel() - g[f"{name}_p"])) < 1e-10
+
+
+def test_oracle_fsg_converged_run(runs):
+    g, meta = runs
+    c = meta["full_N32_Re100"]
+    lvl, total, conv = orc.oracle_fsg(32, 100.0)
+    assert conv and c["metrics"]["converged"]
+    assert abs(total - c["metrics"]["iterations"]) <= 2
+    if total == c["metrics"]["iterations"]:
+        assert np.max(np.abs(lvl.u.ravel() - g["full_N32_Re100_u"])) < 1e-9
+
+
+# ------------------------------------------------------------------------------------- GPU
+def make_fsg(N, Re, **kw):
+    from solvers.spectral.fsg import FSGSolver
+    args = dict(name="spectral_fsg", Re=float(Re), lid_velocity=1.0, Lx=1.0, Ly=1.0, nx=N, ny=N,
+                tolerance=1e-6, max_iterations=500000, basis_type="chebyshev", CFL=1.5, beta_squared=5.0,
+                corner_treatment="smoothing", corner_smoothing=0.15, multigrid="fsg", n_levels=2,
+                coarse_tolerance_factor=1.0, prolongation_method="fft", restriction_method="fft",
+                check_every=512, graph_iters=16)
+    args.update(kw)
+    return FSGSolver(**args)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CAPPED)
+def test_gpu_fsg_capped_runs(runs, name):
+    g, meta = runs
+    c = meta[name]
+    s = make_fsg(c["N"], c["Re"], **c["kw"])
+    s.solve()
+    m, ref = s.metrics, c["metrics"]
+    assert m.iterations == ref["iterations"] and m.converged == ref["converged"]
+    assert np.max(np.abs(s.arrays.u - g[f"{name}_u"])) < 1e-10
+    assert np.max(np.abs(s.arrays.v - g[f"{name}_v"])) < 1e-10
+    assert np.max(np.abs(s.arrays.p - g[f"{name}_p"])) < 1e-10
+    for key in ("final_residual", "u_momentum_residual", "v_momentum_residual", "continuity_residual",
+                "final_energy", "final_enstrophy", "final_palinstrophy", "psi_min", "psi_min_x", "omega_max"):
+        assert getattr(m, key) == pytest.approx(ref[key], rel=1e-7, abs=1e-9), key
+    assert len(s.time_series.rel_iter_residual) == 1 and len(s.time_series.energy) == 1
+
+
+@pytest.mark.gpu
+def test_gpu_fsg_converged_run(runs):
+    g, meta = runs
+    ref = meta["full_N32_Re100"]["metrics"]
+    s = make_fsg(32, 100.0)
+    s.solve()
+    m = s.metrics
+    assert m.converged and abs(m.iterations - ref["iterations"]) <= 2
+    assert m.final_residual == 1e-6
+    if m.iterations == ref["iterations"]:
+        assert np.max(np.abs(s.fields.u - g["full_N32_Re100_u"])) < 1e-9
+    assert m.psi_min == pytest.approx(ref["psi_min"], rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_smoother_matches_oracle_stage_pressure():
+    """One level in smoother mode (stage pressure) against the oracle's stage_pressure=True steps."""
+    from solvers.spectral.sg import SGSolver
+    N, Re, K = 32, 1000.0, 200           # SG diverges here with CFL 1.5 (quirk Q1); the smoother does not
+    s = SGSolver(name="spectral", Re=Re, nx=N, ny=N, basis_type="chebyshev", CFL=1.5, check_every=256, graph_iters=8)
+    s._stage_pressure, s._warmup, s._nan_exit = 1, 0, True
+    rec = s.run_iterations(K, diagnostics=False)
+    o = orc.OracleSG(N, Re, stage_pressure=True)
+    dts = [o.step() for _ in range(K)]
+    assert rec.shape[0] == K and np.all(np.isfinite(rec[:, 0]))
+    assert np.max(np.abs(s.arrays.u.reshape(N + 1, N + 1) - o.u)) < 1e-11
+    assert np.max(np.abs(s.arrays.p.reshape(N - 1, N - 1) - o.p)) < 1e-11
+    assert np.max(np.abs(rec[:, 7] - np.array(dts)) / np.array(dts)) < 1e-12
