@@ -292,8 +292,11 @@ struct StageLds {
 // GP   : also contract the pressure transforms (px, py) and store them
 // LAST : stage 4 -- pressure update, in-place state, reductions (incl. the index-M-1 nodes)
 // DUMP : parity-test mode, writes every intermediate, touches no state
-template <bool GP, bool LAST, bool DUMP>
-__global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs a) {
+// BATCH: blockIdx.y selects one of several independent trials; their argument blocks live in
+//        device memory (a_arr), the single-trial path keeps them in the kernarg segment (a_val)
+template <bool GP, bool LAST, bool DUMP, bool BATCH>
+__global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs a_val, const StageArgs* a_arr) {
+  const StageArgs& a = BATCH ? a_arr[blockIdx.y] : a_val;
   using L = StageLds<GP>;
   constexpr int NA = L::NA;
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -575,8 +578,13 @@ __device__ __forceinline__ double next_dt(double umax, double vmax, const FinalA
 
 // all kThreads threads of one block call this; sm holds kThreads * (PS_N + 2) doubles
 __device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t) {
-  const int done = a.ctrl[LDC_CTRL_DONE], iter = a.ctrl[LDC_CTRL_ITER];
-  const int step = a.ctrl[LDC_CTRL_STEP], flushed = a.ctrl[LDC_CTRL_FLUSHED];
+  __shared__ int fin_state[4];       // one reader: the decision below guards barriers
+  if (t == 0) {
+    fin_state[0] = a.ctrl[LDC_CTRL_DONE]; fin_state[1] = a.ctrl[LDC_CTRL_ITER];
+    fin_state[2] = a.ctrl[LDC_CTRL_STEP]; fin_state[3] = a.ctrl[LDC_CTRL_FLUSHED];
+  }
+  __syncthreads();
+  const int done = fin_state[0], iter = fin_state[1], step = fin_state[2], flushed = fin_state[3];
   const bool flush = a.with_diag && (flushed < iter);             // record iter-1 lacks Z, P
   const bool crit = a.do_critical && !done && (step > iter);       // iteration `iter` awaits its record
   if (!flush && !crit) return;
@@ -647,9 +655,10 @@ __device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t) 
   }
 }
 
-__global__ __launch_bounds__(kThreads) void finalize_kernel(const FinalArgs a) {
+template <bool BATCH>
+__global__ __launch_bounds__(kThreads) void finalize_kernel(const FinalArgs a_val, const FinalArgs* a_arr) {
   __shared__ double sm[kThreads * (PS_N + 2)];
-  fin_work(a, sm, threadIdx.x);
+  fin_work(BATCH ? a_arr[blockIdx.y] : a_val, sm, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -669,7 +678,9 @@ struct PostArgs {
   FinalArgs fin;
 };
 
-__global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a) {
+template <bool BATCH>
+__global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, const PostArgs* a_arr) {
+  const PostArgs& a = BATCH ? a_arr[blockIdx.y] : a_val;
   __shared__ __attribute__((aligned(16))) double red[kThreads * (PS_N + 2)];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int M = a.M, LD = a.LD, T = a.T, nt = T * T, m1 = M - 1;
@@ -679,8 +690,17 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a) {
   // this launch would reproduce bit-identical output, so the whole launch may be skipped.
   // (Blocks may disagree while the finalize block of this very launch flips FLUSHED; that
   // is benign for the same reason.)
-  const int step = a.ctrl[LDC_CTRL_STEP];
-  if (!a.ungated && a.ctrl[LDC_CTRL_DONE] != 0 && a.ctrl[LDC_CTRL_FLUSHED] >= step) return;
+  // The decision must be uniform over the work-group (there are barriers below) although the
+  // flags can flip while this launch runs: ONE thread reads them, everyone uses its answer.
+  __shared__ int gate[2];
+  if (tid == 0) {
+    const int st0 = a.ctrl[LDC_CTRL_STEP];
+    gate[0] = st0;
+    gate[1] = (!a.ungated && a.ctrl[LDC_CTRL_DONE] != 0 && a.ctrl[LDC_CTRL_FLUSHED] >= st0) ? 1 : 0;
+  }
+  __syncthreads();
+  const int step = gate[0];
+  if (gate[1]) return;
   double* partZ = a.partZ0 + (size_t)((step > 0 ? step - 1 : 0) & 1) * a.stride;
 
   if (b < nt) {
@@ -803,13 +823,22 @@ struct PalinArgs {
   int ungated;
 };
 
-__global__ __launch_bounds__(kThreads) void palin_kernel(const PalinArgs a) {
+template <bool BATCH>
+__global__ __launch_bounds__(kThreads) void palin_kernel(const PalinArgs a_val, const PalinArgs* a_arr) {
+  const PalinArgs& a = BATCH ? a_arr[blockIdx.y] : a_val;
   __shared__ __attribute__((aligned(16))) double red[kWaves * 2 * 4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int M = a.M, LD = a.LD, T = a.T, nt = T * T, m1 = M - 1;
   const int b = (int)blockIdx.x;
-  const int step = a.ctrl[LDC_CTRL_STEP];
-  if (!a.ungated && a.ctrl[LDC_CTRL_DONE] != 0 && a.ctrl[LDC_CTRL_FLUSHED] >= step) return;   // see post_kernel
+  __shared__ int gate[2];            // block-uniform decision, see post_kernel
+  if (tid == 0) {
+    const int st0 = a.ctrl[LDC_CTRL_STEP];
+    gate[0] = st0;
+    gate[1] = (!a.ungated && a.ctrl[LDC_CTRL_DONE] != 0 && a.ctrl[LDC_CTRL_FLUSHED] >= st0) ? 1 : 0;
+  }
+  __syncthreads();
+  const int step = gate[0];
+  if (gate[1]) return;
   double* partP = a.partP0 + (size_t)((step > 0 ? step - 1 : 0) & 1) * a.stride;
   double sums[1] = {0.0};
   double dummy[1] = {0.0};
@@ -1038,6 +1067,22 @@ struct ldc_solver {
   hipStream_t capture_stream;
 };
 
+
+// B independent trials of identical geometry advanced by every launch (blockIdx.y = trial).
+struct ldc_batch {
+  int B;
+  std::vector<ldc_solver*> s;
+  StageArgs* d_stage[4];     // device argument arrays, one entry per trial
+  PostArgs* d_post[2];       // [with_diagnostics], inside the loop (with finalize block)
+  PostArgs* d_postT[2];      // T-only launches on PA / PB (smoother mode)
+  PalinArgs* d_palin;
+  FinalArgs* d_flush;
+  int post_grid[2], postT_grid;
+  int iters_per_graph;
+  hipGraphExec_t graph[2];
+  hipStream_t capture_stream;
+};
+
 namespace {
 
 #define HIP_TRY(expr)                         \
@@ -1079,17 +1124,22 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
   return a;
 }
 
-template <bool GP, bool LAST, bool DUMP>
-int launch_stage_variant(const StageArgs& a, int nt, hipStream_t st) {
+template <bool GP, bool LAST, bool DUMP, bool BATCH>
+int launch_stage_kernel(const StageArgs& a, const StageArgs* arr, int nt, int nbatch, hipStream_t st) {
   static bool attr_set = false;   // dynamic LDS above 64 KiB must be enabled once per kernel
-  auto kern = stage_kernel<GP, LAST, DUMP>;
+  auto kern = stage_kernel<GP, LAST, DUMP, BATCH>;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)StageLds<GP>::BYTES));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nt), dim3(kStageThreads), StageLds<GP>::BYTES, st, a);
+  hipLaunchKernelGGL(kern, dim3(nt, nbatch), dim3(kStageThreads), StageLds<GP>::BYTES, st, a, arr);
   return (int)hipGetLastError();
+}
+
+template <bool GP, bool LAST, bool DUMP>
+int launch_stage_variant(const StageArgs& a, int nt, hipStream_t st) {
+  return launch_stage_kernel<GP, LAST, DUMP, false>(a, nullptr, nt, 1, st);
 }
 
 int launch_stage(ldc_solver* s, int k, hipStream_t st) {
@@ -1119,7 +1169,7 @@ FinalArgs make_final_args(const ldc_solver* s, int with_diag, int do_critical) {
 }
 
 // T1T/T2T (+ omega tiles) (+ the finalize block); `loop` = inside the iteration loop
-int launch_post(const ldc_solver* s, const double* P, int do_omega, int loop, int with_diag, hipStream_t st) {
+PostArgs make_post_args(const ldc_solver* s, const double* P, int do_omega, int loop, int with_diag, int* grid_out) {
   const ldc_problem& p = s->p;
   PostArgs a;
   memset(&a, 0, sizeof(a));
@@ -1136,11 +1186,18 @@ int launch_post(const ldc_solver* s, const double* P, int do_omega, int loop, in
     a.fin_block = grid++;
     a.fin = make_final_args(s, with_diag, 1);
   }
-  hipLaunchKernelGGL(post_kernel, dim3(grid), dim3(kThreads), 0, st, a);
+  *grid_out = grid;
+  return a;
+}
+
+int launch_post(const ldc_solver* s, const double* P, int do_omega, int loop, int with_diag, hipStream_t st) {
+  int grid = 0;
+  const PostArgs a = make_post_args(s, P, do_omega, loop, with_diag, &grid);
+  hipLaunchKernelGGL(post_kernel<false>, dim3(grid), dim3(kThreads), 0, st, a, (const PostArgs*)nullptr);
   return (int)hipGetLastError();
 }
 
-int launch_palin(const ldc_solver* s, int loop, hipStream_t st) {
+PalinArgs make_palin_args(const ldc_solver* s, int loop) {
   const ldc_problem& p = s->p;
   PalinArgs a;
   memset(&a, 0, sizeof(a));
@@ -1148,13 +1205,19 @@ int launch_palin(const ldc_solver* s, int loop, hipStream_t st) {
   a.Dx = p.Dx; a.Dy = p.Dy; a.W = p.W; a.WT = p.WT; a.wx = p.wx; a.wy = p.wy;
   a.ctrl = p.ctrl; a.partP0 = p.partials + 3 * p.partials_stride; a.stride = p.partials_stride;
   a.ungated = loop ? 0 : 1;
-  hipLaunchKernelGGL(palin_kernel, dim3(s->nt + s->n_edge_blocks), dim3(kThreads), 0, st, a);
+  return a;
+}
+
+int launch_palin(const ldc_solver* s, int loop, hipStream_t st) {
+  const PalinArgs a = make_palin_args(s, loop);
+  hipLaunchKernelGGL(palin_kernel<false>, dim3(s->nt + s->n_edge_blocks), dim3(kThreads), 0, st, a,
+                     (const PalinArgs*)nullptr);
   return (int)hipGetLastError();
 }
 
 int launch_finalize(const ldc_solver* s, int with_diag, int do_critical, hipStream_t st) {
   const FinalArgs a = make_final_args(s, with_diag, do_critical);
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kThreads), 0, st, a);
+  hipLaunchKernelGGL(finalize_kernel<false>, dim3(1), dim3(kThreads), 0, st, a, (const FinalArgs*)nullptr);
   return (int)hipGetLastError();
 }
 
@@ -1185,6 +1248,63 @@ int build_graph(ldc_solver* s, int with_diag) {
   if (e != 0) { if (g) hipGraphDestroy(g); return e; }
   if (ce != hipSuccess) return (int)ce;
   hipError_t ie = hipGraphInstantiate(&s->graph[with_diag], g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  return (int)ie;
+}
+
+size_t batch_bytes(int B) {
+  auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+  return 4 * up(sizeof(StageArgs) * B) + 4 * up(sizeof(PostArgs) * B) + up(sizeof(PalinArgs) * B) +
+         up(sizeof(FinalArgs) * B);
+}
+
+int batch_launch_stage(ldc_batch* b, int k, hipStream_t st) {
+  const ldc_solver* s0 = b->s[0];
+  const StageArgs dummy = {};
+  const bool sp = s0->p.stage_pressure != 0;
+  if (sp) {
+    if (k < 3) return launch_stage_kernel<true, false, false, true>(dummy, b->d_stage[k], s0->nt, b->B, st);
+    return launch_stage_kernel<true, true, false, true>(dummy, b->d_stage[k], s0->nt, b->B, st);
+  }
+  if (k == 0) return launch_stage_kernel<true, false, false, true>(dummy, b->d_stage[k], s0->nt, b->B, st);
+  if (k < 3) return launch_stage_kernel<false, false, false, true>(dummy, b->d_stage[k], s0->nt, b->B, st);
+  return launch_stage_kernel<false, true, false, true>(dummy, b->d_stage[k], s0->nt, b->B, st);
+}
+
+int batch_launch_iteration(ldc_batch* b, int with_diag, hipStream_t st) {
+  const ldc_solver* s0 = b->s[0];
+  const PostArgs pdummy = {};
+  const PalinArgs qdummy = {};
+  int e;
+  for (int k = 0; k < 4; ++k) {
+    if ((e = batch_launch_stage(b, k, st)) != 0) return e;
+    if (s0->p.stage_pressure && k < 3) {
+      hipLaunchKernelGGL(post_kernel<true>, dim3(b->postT_grid, b->B), dim3(kThreads), 0, st, pdummy,
+                         (const PostArgs*)b->d_postT[k == 1 ? 1 : 0]);
+      if ((e = (int)hipGetLastError()) != 0) return e;
+    }
+  }
+  hipLaunchKernelGGL(post_kernel<true>, dim3(b->post_grid[with_diag], b->B), dim3(kThreads), 0, st, pdummy,
+                     (const PostArgs*)b->d_post[with_diag]);
+  if ((e = (int)hipGetLastError()) != 0) return e;
+  if (with_diag) {
+    hipLaunchKernelGGL(palin_kernel<true>, dim3(s0->nt + s0->n_edge_blocks, b->B), dim3(kThreads), 0, st, qdummy,
+                       (const PalinArgs*)b->d_palin);
+    if ((e = (int)hipGetLastError()) != 0) return e;
+  }
+  return 0;
+}
+
+int batch_build_graph(ldc_batch* b, int with_diag) {
+  if (b->capture_stream == nullptr) HIP_TRY(hipStreamCreateWithFlags(&b->capture_stream, hipStreamNonBlocking));
+  hipGraph_t g = nullptr;
+  HIP_TRY(hipStreamBeginCapture(b->capture_stream, hipStreamCaptureModeThreadLocal));
+  int e = 0;
+  for (int it = 0; it < b->iters_per_graph && e == 0; ++it) e = batch_launch_iteration(b, with_diag, b->capture_stream);
+  hipError_t ce = hipStreamEndCapture(b->capture_stream, &g);
+  if (e != 0) { if (g) hipGraphDestroy(g); return e; }
+  if (ce != hipSuccess) return (int)ce;
+  hipError_t ie = hipGraphInstantiate(&b->graph[with_diag], g, nullptr, nullptr, 0);
   hipGraphDestroy(g);
   return (int)ie;
 }
@@ -1333,6 +1453,97 @@ int ldc_solver_enqueue(ldc_solver* s, int n_iters, int with_diag, void* stream) 
   for (; left > 0; --left) { int e = launch_iteration(s, with_diag, st); if (e) return e; }
   // close the last record (idempotent: folds Z/P only if a record is still open)
   return with_diag ? launch_finalize(s, 1, 0, st) : 0;
+}
+
+size_t ldc_batch_workspace_bytes(int n_trials) { return n_trials > 0 ? batch_bytes(n_trials) : 0; }
+
+int ldc_batch_create(ldc_solver* const* solvers, int n_trials, void* workspace, size_t workspace_bytes,
+                     ldc_batch** out) {
+  if (!solvers || !out || !workspace || n_trials < 1 || n_trials > 4096) return LDC_E_ARG;
+  if (workspace_bytes < batch_bytes(n_trials) || (reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return LDC_E_ARG;
+  const ldc_solver* s0 = solvers[0];
+  if (!s0) return LDC_E_STATE;
+  for (int q = 0; q < n_trials; ++q) {
+    const ldc_solver* t = solvers[q];
+    if (!t) return LDC_E_STATE;
+    if (t->p.M != s0->p.M || t->p.LD != s0->p.LD || t->p.stage_pressure != s0->p.stage_pressure) return LDC_E_ARG;
+  }
+  ldc_batch* b = new (std::nothrow) ldc_batch;
+  if (!b) return LDC_E_STATE;
+  b->B = n_trials;
+  b->s.assign(solvers, solvers + n_trials);
+  b->iters_per_graph = s0->iters_per_graph;
+  b->graph[0] = b->graph[1] = nullptr;
+  b->capture_stream = nullptr;
+  auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+  char* w = static_cast<char*>(workspace);
+  auto carve = [&](size_t bytes) { char* r = w; w += up(bytes); return r; };
+  hipError_t he = hipSuccess;
+  auto put = [&](void* dst, const void* src, size_t bytes) {
+    if (he == hipSuccess) he = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+  };
+  for (int k = 0; k < 4; ++k) {
+    std::vector<StageArgs> h(n_trials);
+    for (int q = 0; q < n_trials; ++q) h[q] = make_stage_args(solvers[q], k);
+    b->d_stage[k] = reinterpret_cast<StageArgs*>(carve(sizeof(StageArgs) * n_trials));
+    put(b->d_stage[k], h.data(), sizeof(StageArgs) * n_trials);
+  }
+  for (int wd = 0; wd < 2; ++wd) {
+    std::vector<PostArgs> h(n_trials);
+    for (int q = 0; q < n_trials; ++q) h[q] = make_post_args(solvers[q], solvers[q]->p.P, wd, 1, wd, &b->post_grid[wd]);
+    b->d_post[wd] = reinterpret_cast<PostArgs*>(carve(sizeof(PostArgs) * n_trials));
+    put(b->d_post[wd], h.data(), sizeof(PostArgs) * n_trials);
+  }
+  for (int ab = 0; ab < 2; ++ab) {
+    std::vector<PostArgs> h(n_trials);
+    for (int q = 0; q < n_trials; ++q)
+      h[q] = make_post_args(solvers[q], ab == 0 ? solvers[q]->p.PA : solvers[q]->p.PB, 0, 0, 0, &b->postT_grid);
+    b->d_postT[ab] = reinterpret_cast<PostArgs*>(carve(sizeof(PostArgs) * n_trials));
+    put(b->d_postT[ab], h.data(), sizeof(PostArgs) * n_trials);
+  }
+  {
+    std::vector<PalinArgs> h(n_trials);
+    for (int q = 0; q < n_trials; ++q) h[q] = make_palin_args(solvers[q], 1);
+    b->d_palin = reinterpret_cast<PalinArgs*>(carve(sizeof(PalinArgs) * n_trials));
+    put(b->d_palin, h.data(), sizeof(PalinArgs) * n_trials);
+    std::vector<FinalArgs> f(n_trials);
+    for (int q = 0; q < n_trials; ++q) f[q] = make_final_args(solvers[q], 1, 0);
+    b->d_flush = reinterpret_cast<FinalArgs*>(carve(sizeof(FinalArgs) * n_trials));
+    put(b->d_flush, f.data(), sizeof(FinalArgs) * n_trials);
+  }
+  if (he != hipSuccess) { delete b; return (int)he; }
+  *out = b;
+  return 0;
+}
+
+int ldc_batch_destroy(ldc_batch* b) {
+  if (!b) return LDC_E_STATE;
+  for (int q = 0; q < 2; ++q) if (b->graph[q]) hipGraphExecDestroy(b->graph[q]);
+  if (b->capture_stream) hipStreamDestroy(b->capture_stream);
+  delete b;
+  return 0;
+}
+
+int ldc_batch_enqueue(ldc_batch* b, int n_iters, int with_diag, void* stream) {
+  if (!b) return LDC_E_STATE;
+  if (n_iters < 0) return LDC_E_ARG;
+  with_diag = with_diag ? 1 : 0;
+  hipStream_t st = as_stream(stream);
+  int left = n_iters;
+  if (left >= b->iters_per_graph) {
+    if (!b->graph[with_diag]) { int e = batch_build_graph(b, with_diag); if (e) return e; }
+    while (left >= b->iters_per_graph) {
+      HIP_TRY(hipGraphLaunch(b->graph[with_diag], st));
+      left -= b->iters_per_graph;
+    }
+  }
+  for (; left > 0; --left) { int e = batch_launch_iteration(b, with_diag, st); if (e) return e; }
+  if (with_diag) {
+    const FinalArgs fdummy = {};
+    hipLaunchKernelGGL(finalize_kernel<true>, dim3(1, b->B), dim3(kThreads), 0, st, fdummy, (const FinalArgs*)b->d_flush);
+    return (int)hipGetLastError();
+  }
+  return 0;
 }
 
 int ldc_residual_debug(ldc_solver* s, int which, double* const out[11], void* stream) {

@@ -74,6 +74,11 @@ def lib() -> C.CDLL:
     L.ldc_global_quantities.argtypes = [_dp, _dp, _dp]
     L.ldc_prime.argtypes = [_dp, _dp]
     L.ldc_solver_enqueue.argtypes = [_dp, C.c_int, C.c_int, _dp]
+    L.ldc_batch_workspace_bytes.argtypes = [C.c_int]
+    L.ldc_batch_workspace_bytes.restype = C.c_size_t
+    L.ldc_batch_create.argtypes = [C.POINTER(_dp), C.c_int, _dp, C.c_size_t, C.POINTER(_dp)]
+    L.ldc_batch_destroy.argtypes = [_dp]
+    L.ldc_batch_enqueue.argtypes = [_dp, C.c_int, C.c_int, _dp]
     L.ldc_residual_debug.argtypes = [_dp, C.c_int, C.POINTER(_dp), _dp]
     L.ldc_gemm_nt.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
     L.ldc_poisson_fastdiag.argtypes = [_dp] * 10 + [C.c_int, C.c_int, _dp]
@@ -82,7 +87,7 @@ def lib() -> C.CDLL:
     L.ldc_mfma_selftest.argtypes = [_dp, _dp, _dp, _dp]
     L.ldc_mfma_peak.argtypes = [_dp, C.c_int, C.c_int, _dp]
     for name in EXPORTS:
-        if name not in ("ldc_version", "ldc_error_string"):
+        if name not in ("ldc_version", "ldc_error_string", "ldc_batch_workspace_bytes"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -93,6 +98,7 @@ EXPORTS = (
     "ldc_version", "ldc_error_string", "ldc_device_check", "ldc_solver_create", "ldc_solver_destroy",
     "ldc_stage", "ldc_pressure_transform", "ldc_diagnostics", "ldc_finalize", "ldc_prime", "ldc_global_quantities",
     "ldc_solver_enqueue", "ldc_solver_set_graph_iters", "ldc_residual_debug", "ldc_gemm_nt",
+    "ldc_batch_workspace_bytes", "ldc_batch_create", "ldc_batch_destroy", "ldc_batch_enqueue",
     "ldc_poisson_fastdiag", "ldc_vortex_extrema", "ldc_mfma_selftest", "ldc_mfma_peak", "ldc_debug_ablate",
 )
 

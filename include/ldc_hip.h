@@ -24,6 +24,7 @@
 #ifndef LDC_HIP_H
 #define LDC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -146,6 +147,19 @@ int ldc_prime(ldc_solver *s, void *stream);
 int ldc_solver_enqueue(ldc_solver *s, int n_iters, int with_diagnostics, void *stream);
 /* iterations captured per graph (default 32); must be set before the first enqueue      */
 int ldc_solver_set_graph_iters(ldc_solver *s, int iters_per_graph);
+
+/* batched trials (the sweep axis of the reference on ONE GPU): n_trials solver handles of      */
+/* identical geometry (M, LD, mode) advanced by the same launches, blockIdx.y = trial; each     */
+/* keeps its own state, dt, latch and history.  `workspace` = caller-owned DEVICE memory,        */
+/* 256-byte aligned, at least ldc_batch_workspace_bytes(n_trials) bytes, alive as long as the    */
+/* batch; it receives the per-trial kernel argument blocks (one synchronous copy at creation).   */
+typedef struct ldc_batch ldc_batch;
+size_t ldc_batch_workspace_bytes(int n_trials);
+int ldc_batch_create(ldc_solver *const *solvers, int n_trials, void *workspace, size_t workspace_bytes,
+                     ldc_batch **out);
+int ldc_batch_destroy(ldc_batch *b);
+/* n_iters iterations of base.py:243-313 for every trial that is not latched yet                 */
+int ldc_batch_enqueue(ldc_batch *b, int n_iters, int with_diagnostics, void *stream);
 
 /* debugging aid for parity tests: one residual evaluation of state `which`              */
 /* (0: U/V, 1: UA/VA, 2: UB/VB) with every intermediate written to LD x LD arrays:       */

@@ -24,6 +24,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--N", type=int, default=256)
 ap.add_argument("--Re", type=float, default=1000.0)
 ap.add_argument("--reps", type=int, default=200)
+ap.add_argument("--batched", action="store_true")
 a = ap.parse_args()
 s = SGSolver(name="spectral", Re=a.Re, nx=a.N, ny=a.N, basis_type="chebyshev", CFL=1.5, tolerance=0.0,
              max_iterations=10**9, check_every=4096, graph_iters=32)
@@ -82,3 +83,19 @@ for nd in (0, 1):
     med, best = burst(lambda: lib.ldc_solver_enqueue(h, 32, nd, st), reps=10)
     print(f"graph iteration diag={nd}: {med / 32:8.2f} us/iter  ({32e6 / med:9.1f} it/s)")
 s.close()
+
+# ---- batched trials: aggregate trial-iterations/s when B trials share every launch -------------
+if "--batched" in sys.argv:
+    from solvers.spectral.batched import BatchedSGSolver
+    for N, Bs in ((32, (1, 16, 64)), (64, (1, 4, 16)), (128, (1, 2, 4))):
+        for B in Bs:
+            trials = [dict(name="spectral", Re=100.0 + 50 * q, nx=N, ny=N, basis_type="chebyshev", CFL=1.5,
+                           corner_smoothing=0.05 + 0.01 * (q % 20), tolerance=0.0, max_iterations=10**9,
+                           check_every=1024, graph_iters=32) for q in range(B)]
+            b = BatchedSGSolver(trials)
+            b.run_iterations(200)
+            t0 = __import__("time").perf_counter()
+            b.run_iterations(1024)
+            dt = __import__("time").perf_counter() - t0
+            print(f"batched N={N:4d} B={B:3d}: {dt / 1024 * 1e6:8.2f} us/iteration, {B * 1024 / dt:10.0f} trial-iterations/s")
+            b.close()
