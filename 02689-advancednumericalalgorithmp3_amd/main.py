@@ -48,17 +48,11 @@ def _jsonable(x):
     return x
 
 
-def run_solver(cfg: dict, out_dir: Path, device: str = None) -> dict:
-    """Instantiate cfg.solver, solve, validate; returns the result record (reference main.py:75-120)."""
+def make_record(cfg: dict, solver, out_dir: Path, t0: float) -> dict:
+    """Everything the reference does after solve() (main.py:99-119): validation, objective, artefacts."""
     from solvers import validation as V
-    node = dict(cfg["solver"])
-    if device is not None:
-        node["device"] = device
-    solver = C.instantiate(node)
     name = cfg["solver"]["name"]
     n_display = cfg["N"] + 1 if str(name).startswith("spectral") else cfg["N"]
-    t0 = time.perf_counter()
-    solver.solve()
     errors = solver.compute_validation_errors(reference_dir=cfg.get("validation", {}).get("reference_dir", "data/validation/fv"))
     objective_kind = cfg.get("optuna", {}).get("objective", "fv_l2_error")
     objective = V.compute_optuna_objective(
@@ -82,9 +76,38 @@ def run_solver(cfg: dict, out_dir: Path, device: str = None) -> dict:
         log.warning("VTS export failed: %s", exc)
     _mlflow_log(cfg, rec, solver)
     log.info("Done: %d iter, converged=%s, time=%.2fs", m.iterations, m.converged, m.wall_time_seconds)
+    return rec
+
+
+def run_solver(cfg: dict, out_dir: Path, device: str = None) -> dict:
+    """Instantiate cfg.solver, solve, validate; returns the result record (reference main.py:75-120)."""
+    node = dict(cfg["solver"])
+    if device is not None:
+        node["device"] = device
+    solver = C.instantiate(node)
+    t0 = time.perf_counter()
+    solver.solve()
+    rec = make_record(cfg, solver, out_dir, t0)
     if hasattr(solver, "close"):
         solver.close()
     return rec
+
+
+def run_batch(cfgs: list, out_dirs: list, device: str = None) -> list:
+    """Several SG trials of equal N on one GPU, advanced by the same launches (solvers.spectral.batched)."""
+    from solvers.spectral.batched import BatchedSGSolver
+    nodes = []
+    for cfg in cfgs:
+        node = {k: v for k, v in cfg["solver"].items() if k != "_target_"}
+        if device is not None:
+            node["device"] = device
+        nodes.append(node)
+    t0 = time.perf_counter()
+    batch = BatchedSGSolver(nodes)
+    batch.solve()
+    recs = [make_record(cfg, s, d, t0) for cfg, s, d in zip(cfgs, batch.solvers, out_dirs)]
+    batch.close()
+    return recs
 
 
 def _mlflow_log(cfg, rec, solver):
@@ -136,20 +159,38 @@ def main(argv=None) -> float | None:
     root_dir = time.strftime(str(root_tpl).replace("${now:", "").replace("}", ""), time.localtime())
     root_dir = Path(dist.all_gather_object(root_dir)[0])          # every rank uses rank 0's timestamp
 
-    def run_one(assignment, index):
+    SG = "solvers.spectral.sg.SGSolver"
+    max_batch = int(os.environ.get("LDC_MAX_BATCH", stamp_cfg.get("hydra", {}).get("launcher", {}).get("batch_trials", 64)))
+
+    def job_cfg(assignment, index):
         cfg = C.compose_job(composer, overrides, list(fixed) + list(assignment))
         cfg.setdefault("hydra", {}).setdefault("job", {})["num"] = index
-        C.resolve(cfg)
-        log.info("Solver: %s, N=%s, Re=%s %s", cfg["solver"]["name"], cfg["N"], cfg["Re"],
-                 dict(assignment) if assignment else "")
-        rec = run_solver(cfg, root_dir / str(index), device=device)
-        rec["overrides"] = {k: v for k, v in assignment}
-        return rec
+        return C.resolve(cfg)
+
+    def run_group(items, jobs, offset=0):
+        """items: [(index, trial)] owned by this rank with one group key; SG trials of equal N share launches."""
+        cfgs = [job_cfg(jobs[i], offset + i) for i, _ in items]
+        out = []
+        if all(c["solver"]["_target_"] == SG for c in cfgs) and len(cfgs) > 1 and max_batch > 1:
+            for lo in range(0, len(cfgs), max_batch):
+                part = cfgs[lo: lo + max_batch]
+                log.info("batch of %d trials at N=%s on %s", len(part), part[0]["N"], device or "cuda:0")
+                recs = run_batch(part, [root_dir / str(offset + i) for i, _ in items[lo: lo + max_batch]], device)
+                out.extend(recs)
+        else:
+            for (i, _), cfg in zip(items, cfgs):
+                out.append(run_solver(cfg, root_dir / str(offset + i), device=device))
+        for (i, _), r in zip(items, out):
+            r["overrides"] = {k: v for k, v in jobs[i]}
+        return out
+
+    def key_of(jobs):
+        return lambda t: (t.get("N"), str(dict(jobs[t["_job"]]).get("solver", "")))
 
     if not search:
         jobs = C.expand_grid(space)
-        trials = [dict(a, N=dict(a).get("N", base_cfg.get("N", 32))) for a in jobs]
-        recs = run_farm(trials, lambda t, i: run_one(jobs[i], i), dist)
+        trials = [dict(a, N=dict(a).get("N", base_cfg.get("N", 32)), _job=i) for i, a in enumerate(jobs)]
+        recs = run_farm(trials, None, dist, run_group=lambda items: run_group(items, jobs), group_key=key_of(jobs))
         objective = recs[0]["objective"] if len(recs) == 1 else None
     else:
         sw = stamp_cfg.get("hydra", {}).get("sweeper", {}) or {}
@@ -160,7 +201,9 @@ def main(argv=None) -> float | None:
         while done < n_trials:
             batch = [sampler.ask() for _ in range(min(n_jobs, n_trials - done))]
             jobs = [list(b.items()) for b in batch]
-            out = run_farm([dict(b) for b in batch], lambda t, i: run_one(jobs[i], done + i), dist)
+            trials = [dict(b, N=b.get("N", base_cfg.get("N", 32)), _job=i) for i, b in enumerate(batch)]
+            out = run_farm(trials, None, dist, run_group=lambda items: run_group(items, jobs, done),
+                           group_key=key_of(jobs))
             for b, r in zip(batch, out):
                 sampler.tell(b, r["objective"] if isinstance(r["objective"], (int, float)) else math.inf)
             recs.extend(out)

@@ -77,18 +77,30 @@ class Dist:
             self._pg = None
 
 
-def run_farm(trials: list, run_trial, dist: Dist, cost=trial_cost) -> list:
+def run_farm(trials: list, run_trial, dist: Dist, cost=trial_cost, run_group=None, group_key=None) -> list:
     """Run every trial exactly once; returns the list of result records on every rank, in trial order.
 
     ``run_trial(trial, index)`` -> JSON-able dict.  Scheduling is static LPT computed identically on all
-    ranks, so no work needs to be communicated."""
+    ranks, so no work needs to be communicated.  With ``run_group`` the trials a rank owns are grouped by
+    ``group_key(trial)`` and handed over together -- ``run_group([(index, trial), ...]) -> [record, ...]`` --
+    so that equal-N trials can share every kernel launch on that GPU (solvers.spectral.batched)."""
     owner = assign_lpt([cost(t) for t in trials], dist.world)
     mine = {}
-    for idx, t in enumerate(trials):
-        if owner[idx] == dist.rank:
-            t0 = time.perf_counter()
-            rec = dict(run_trial(t, idx))
-            rec.update(trial_index=idx, rank=dist.rank, trial_seconds=time.perf_counter() - t0)
+    my = [(idx, t) for idx, t in enumerate(trials) if owner[idx] == dist.rank]
+    if run_group is None:
+        groups = [[it] for it in my]
+    else:
+        by_key = {}
+        for it in my:
+            by_key.setdefault(group_key(it[1]) if group_key else None, []).append(it)
+        groups = list(by_key.values())
+    for grp in groups:
+        t0 = time.perf_counter()
+        recs = run_group(grp) if run_group is not None else [run_trial(grp[0][1], grp[0][0])]
+        dt = time.perf_counter() - t0
+        for (idx, _), rec in zip(grp, recs):
+            rec = dict(rec)
+            rec.update(trial_index=idx, rank=dist.rank, trial_seconds=dt, batch_size=len(grp))
             mine[idx] = rec
     merged = {}
     for part in dist.all_gather_object(mine):

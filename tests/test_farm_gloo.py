@@ -61,3 +61,17 @@ def test_two_rank_gloo_farm(tmp_path):
     r0, r1 = (json.loads((tmp_path / f"rank{k}.json").read_text()) for k in (0, 1))
     assert r0 == r1 and r0["n"] == 12
     assert res["best"] <= min(h for hh in res["hist"][:2] for h in hh)
+
+
+def test_farm_groups_equal_n_trials_for_batching():
+    d = Dist()
+    trials = [dict(N=16, Re=r) for r in (1, 2, 3)] + [dict(N=32, Re=9)]
+    seen = []
+
+    def run_group(items):
+        seen.append([i for i, _ in items])
+        return [dict(v=t["Re"]) for _, t in items]
+
+    out = run_farm(trials, None, d, run_group=run_group, group_key=lambda t: t["N"])
+    assert seen == [[0, 1, 2], [3]]
+    assert [r["v"] for r in out] == [1, 2, 3, 9] and [r["batch_size"] for r in out] == [3, 3, 3, 1]
