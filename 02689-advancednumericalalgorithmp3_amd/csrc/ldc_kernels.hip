@@ -135,6 +135,9 @@ struct StageArgs {
   double *Uout, *UoutT, *Vout, *VoutT, *Pout;
   const double *ulid, *wx, *wy;
   const double *DxL, *D2xL, *DyL, *D2yL;   // last columns (index M-1) of the four operators
+  double *W, *WT;                         // vorticity (+ transposed copy): written by DIAG 1, read by DIAG 2
+  double *partZ0, *partP0;                // parity slabs of the enstrophy / palinstrophy partial sums
+  long long stride;
   const double* scal;
   int* ctrl;
   double* partials;
@@ -168,6 +171,8 @@ __device__ __forceinline__ double quad_sum(double x) {
 struct RoleOps {
   const double *A0, *A1, *B0, *B1, *A2, *B2;
   int ablate;
+  int role; // 0: x-derivative chains, 1: y-derivative chains
+  int x4;   // fifth contraction: 0: A2.B2 (grad p)   1: A0.B2 (d omega/dx = Dx . WT)   2: A2.B0 (d omega/dy = W . Dy)
 };
 
 template <bool GP>
@@ -184,11 +189,14 @@ __device__ __forceinline__ void load_role(RoleFrags<GP>& f, const RoleOps& o, in
   }
   f.a0 = ldfrag(o.A0, LD, r0, k0, lane); f.a1 = ldfrag(o.A1, LD, r0, k0, lane);
   f.b0 = ldfrag(o.B0, LD, c0, k0, lane); f.b1 = ldfrag(o.B1, LD, c0, k0, lane);
-  if (GP) { f.a2 = ldfrag(o.A2, LD, r0, k0, lane); f.b2 = ldfrag(o.B2, LD, c0, k0, lane); }
+  if (GP) {   // GP here means "has a fifth contraction"
+    if (o.x4 != 1) f.a2 = ldfrag(o.A2, LD, r0, k0, lane);
+    if (o.x4 != 2) f.b2 = ldfrag(o.B2, LD, c0, k0, lane);
+  }
 }
 
 template <bool GP, int NA>
-__device__ __forceinline__ void mfma_role(const RoleFrags<GP>& f, v4d (&acc)[NA], int ablate) {
+__device__ __forceinline__ void mfma_role(const RoleFrags<GP>& f, v4d (&acc)[NA], int ablate, int x4) {
   if (ablate & 1) {   // keep the operands live without issuing MFMAs
     acc[0][0] += f.a0[0] + f.b0[1] + f.a1[2] + f.b1[3];
     if (GP) acc[4][0] += f.a2[0] + f.b2[0];
@@ -200,7 +208,11 @@ __device__ __forceinline__ void mfma_role(const RoleFrags<GP>& f, v4d (&acc)[NA]
     acc[1] = MFMA_F64(f.a0[s], f.b1[s], acc[1]);
     acc[2] = MFMA_F64(f.a1[s], f.b0[s], acc[2]);
     acc[3] = MFMA_F64(f.a1[s], f.b1[s], acc[3]);
-    if (GP) acc[4] = MFMA_F64(f.a2[s], f.b2[s], acc[4]);
+    if (GP) {
+      const double x = (x4 == 1) ? f.a0[s] : f.a2[s];
+      const double y = (x4 == 2) ? f.b0[s] : f.b2[s];
+      acc[4] = MFMA_F64(x, y, acc[4]);
+    }
   }
 }
 
@@ -215,37 +227,52 @@ struct EdgeAcc {
   double er[5], ec[5], ek[5];
 };
 
-// VEL: the four velocity contractions (needed where R_u, R_v are formed: LAST, DUMP)
-// GP : the pressure-gradient contraction (stage 1 stores it for the later stages)
-template <bool VEL, bool GP>
+// VEL: 1 = the four velocity contractions (R_u, R_v at the nodes: LAST, DUMP)
+//      2 = ONE contraction in slot 0, the one the vorticity needs from this role (DIAG 1):
+//          role 0: A0.B1 = Dx . VT (dv/dx)      role 1: A0.B0 = U . Dy (du/dy)
+// GP : the fifth contraction (grad p, or grad omega by o.x4)
+template <int VEL, bool GP>
 __device__ __forceinline__ void edge_group(EdgeAcc& e, const RoleFrags<GP>& f, const RoleOps& o, int LD, int m1,
                                            int k0, int lane, bool rowE, bool colE) {
   const size_t off = (size_t)m1 * LD + k0 + 4 * (lane >> 4);
-  v4d ar0, ar1, ar2, bc0, bc1, bc2;
+  auto row_of = [&](const double* X) { return *reinterpret_cast<const v4d*>(X + off); };
+  v4d ar0, ar1, xr, bc0, bc1, yc;
+  const bool need_a0_row = (VEL != 0) || (GP && o.x4 == 1);
+  const bool need_b0_col = (VEL == 1) || (VEL == 2 && o.role == 1) || (GP && o.x4 == 2);
+  const bool need_b1_col = (VEL == 1) || (VEL == 2 && o.role == 0);
   if (rowE) {
-    if (VEL) {
-      ar0 = *reinterpret_cast<const v4d*>(o.A0 + off);
-      ar1 = *reinterpret_cast<const v4d*>(o.A1 + off);
+    if (need_a0_row) ar0 = row_of(o.A0);
+    if (VEL == 1) {
+      ar1 = row_of(o.A1);
       e.er[0] += dot4(ar0, f.b0); e.er[1] += dot4(ar0, f.b1);
       e.er[2] += dot4(ar1, f.b0); e.er[3] += dot4(ar1, f.b1);
     }
-    if (GP) { ar2 = *reinterpret_cast<const v4d*>(o.A2 + off); e.er[4] += dot4(ar2, f.b2); }
+    if (VEL == 2) e.er[0] += dot4(ar0, o.role == 0 ? f.b1 : f.b0);
+    if (GP) {
+      xr = (o.x4 == 1) ? ar0 : row_of(o.A2);
+      e.er[4] += dot4(xr, (o.x4 == 2) ? f.b0 : f.b2);
+    }
   }
   if (colE) {
-    if (VEL) {
-      bc0 = *reinterpret_cast<const v4d*>(o.B0 + off);
-      bc1 = *reinterpret_cast<const v4d*>(o.B1 + off);
+    if (need_b0_col) bc0 = row_of(o.B0);
+    if (need_b1_col) bc1 = row_of(o.B1);
+    if (VEL == 1) {
       e.ec[0] += dot4(f.a0, bc0); e.ec[1] += dot4(f.a0, bc1);
       e.ec[2] += dot4(f.a1, bc0); e.ec[3] += dot4(f.a1, bc1);
     }
-    if (GP) { bc2 = *reinterpret_cast<const v4d*>(o.B2 + off); e.ec[4] += dot4(f.a2, bc2); }
+    if (VEL == 2) e.ec[0] += dot4(f.a0, o.role == 0 ? bc1 : bc0);
+    if (GP) {
+      yc = (o.x4 == 2) ? bc0 : row_of(o.B2);
+      e.ec[4] += dot4((o.x4 == 1) ? f.a0 : f.a2, yc);
+    }
   }
   if (rowE && colE) {
-    if (VEL) {
+    if (VEL == 1) {
       e.ek[0] += dot4(ar0, bc0); e.ek[1] += dot4(ar0, bc1);
       e.ek[2] += dot4(ar1, bc0); e.ek[3] += dot4(ar1, bc1);
     }
-    if (GP) e.ek[4] += dot4(ar2, bc2);
+    if (VEL == 2) e.ek[0] += dot4(ar0, o.role == 0 ? bc1 : bc0);
+    if (GP) e.ek[4] += dot4(xr, yc);
   }
 }
 
@@ -283,8 +310,8 @@ struct StageLds {
   static constexpr int NA = GP ? 5 : 4;
   static constexpr int RED = kStageWaves * NA * 4 * 64;
   static constexpr int EDGE = RED;                         // [wave][15][16]
-  static constexpr int TILE = EDGE + kStageWaves * 15 * 16;  // 2 x 16 x 17
-  static constexpr int SCR = TILE + 2 * 16 * 17;           // kStageWaves * PS_N
+  static constexpr int TILE = EDGE + kStageWaves * 15 * 16;  // 3 x 16 x 17
+  static constexpr int SCR = TILE + 3 * 16 * 17;           // kStageWaves * PS_N
   static constexpr int TOTAL = SCR + kStageWaves * PS_N;
   static constexpr size_t BYTES = sizeof(double) * TOTAL;
 };
@@ -294,9 +321,15 @@ struct StageLds {
 // DUMP : parity-test mode, writes every intermediate, touches no state
 // BATCH: blockIdx.y selects one of several independent trials; their argument blocks live in
 //        device memory (a_arr), the single-trial path keeps them in the kernarg segment (a_val)
-template <bool GP, bool LAST, bool DUMP, bool BATCH>
+// DIAG : 0 none; 1 (stage 1 of iteration n+1) vorticity of phi^(n+1) = dv/dx - du/dy, which this stage
+//        forms anyway, its enstrophy partial sums and the omega / omega^T arrays; 2 (stage 2) the two
+//        contractions Dx.omega, omega.Dy^T and the palinstrophy partial sums.  Both belong to the record
+//        of iteration n and are folded by the finalize block of the next post launch.
+template <bool GPV, bool LAST, bool DUMP, bool BATCH, int DIAG>
 __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs a_val, const StageArgs* a_arr) {
   const StageArgs& a = BATCH ? a_arr[blockIdx.y] : a_val;
+  constexpr bool GP = GPV || (DIAG == 2);      // "has a fifth contraction" (grad p or grad omega)
+  static_assert(!(GPV && DIAG == 2), "stage 2 of SG carries no pressure contraction");
   using L = StageLds<GP>;
   constexpr int NA = L::NA;
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -309,15 +342,17 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   int I, J;
   tile_of_block((int)blockIdx.x, T, I, J);
   const int r0 = 16 * I, c0 = 16 * J;
-  constexpr bool VEL = LAST || DUMP;          // nodes of index M-1 need R_u, R_v here
-  constexpr bool EDGES = GP || VEL;
+  constexpr int VEL = (LAST || DUMP) ? 1 : (DIAG == 1 ? 2 : 0);   // what the nodes of index M-1 need here
+  constexpr bool EDGES = GP || (VEL != 0);
   const bool rowE = EDGES && a.tail && (I == T - 1);
   const bool colE = EDGES && a.tail && (J == T - 1);
 
   RoleOps o;
   o.ablate = a.ablate;
-  if (role == 0) { o.A0 = a.Dx; o.A1 = a.D2x; o.B0 = a.UinT; o.B1 = a.VinT; o.A2 = a.GxF; o.B2 = a.T1T; }
-  else           { o.A0 = a.Uin; o.A1 = a.Vin; o.B0 = a.Dy; o.B1 = a.D2y; o.A2 = a.IxF; o.B2 = a.T2T; }
+  o.role = role;
+  o.x4 = (DIAG == 2) ? (role == 0 ? 1 : 2) : 0;
+  if (role == 0) { o.A0 = a.Dx; o.A1 = a.D2x; o.B0 = a.UinT; o.B1 = a.VinT; o.A2 = a.GxF; o.B2 = (DIAG == 2) ? a.WT : a.T1T; }
+  else           { o.A0 = a.Uin; o.A1 = a.Vin; o.B0 = a.Dy; o.B1 = a.D2y; o.A2 = (DIAG == 2) ? a.W : a.IxF; o.B2 = a.T2T; }
 
   // ---- first fragments in flight before anything else ------------------------------------
   int g = kq;
@@ -335,19 +370,20 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   const size_t ij = (size_t)i * LD + j;
   const bool owner = tid < 256;
   double uin = 0, vin = 0, u0 = 0, v0 = 0, p0 = 0, px = 0, py = 0;
-  double dxl = 0, d2xl = 0, dyl = 0, d2yl = 0, ue = 0, ve = 0, un_ = 0, vn_ = 0, lidv = 0, wq = 0;
+  double dxl = 0, d2xl = 0, dyl = 0, d2yl = 0, ue = 0, ve = 0, un_ = 0, vn_ = 0, lidv = 0, wq = 0, we = 0, wn = 0;
   if (owner) {
     uin = a.Uin[ij]; vin = a.Vin[ij];
     if (!DUMP) { u0 = a.U0[ij]; v0 = a.V0[ij]; }
     if (!DUMP && a.Pout != nullptr) p0 = a.P0[ij];
-    if (!GP) { px = a.PX[ij]; py = a.PY[ij]; }
+    if (!GPV) { px = a.PX[ij]; py = a.PY[ij]; }
     if (a.tail) {
       dxl = a.DxL[i]; d2xl = a.D2xL[i]; dyl = a.DyL[j]; d2yl = a.D2yL[j];
       ue = a.Uin[(size_t)m1 * LD + j]; ve = a.Vin[(size_t)m1 * LD + j];    // east-wall row
       un_ = a.Uin[(size_t)i * LD + m1]; vn_ = a.Vin[(size_t)i * LD + m1];  // lid column
+      if (DIAG == 2) { we = a.W[(size_t)m1 * LD + j]; wn = a.W[(size_t)i * LD + m1]; }
     }
     lidv = a.ulid[i];
-    if (LAST) wq = a.wx[i] * a.wy[j];
+    if (LAST || DIAG != 0) wq = a.wx[i] * a.wy[j];
   }
 
   // ---- contraction over k: this wave's quarter, loads one group ahead (A/B ping-pong) --------
@@ -360,11 +396,11 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   for (; g < T; g += 2 * 4) {
     const int g1 = g + 4, g2 = g + 8;
     load_role<GP>(fb, o, LD, r0, c0, 16 * (g1 < T ? g1 : g), lane);   // clamped: harmless reload
-    mfma_role<GP, NA>(fa, acc, a.ablate);
+    mfma_role<GP, NA>(fa, acc, a.ablate, o.x4);
     if (rowE || colE) edge_group<VEL, GP>(ea, fa, o, LD, m1, 16 * g, lane, rowE, colE);
     if (g1 < T) {
       load_role<GP>(fa, o, LD, r0, c0, 16 * (g2 < T ? g2 : g1), lane);
-      mfma_role<GP, NA>(fb, acc, a.ablate);
+      mfma_role<GP, NA>(fb, acc, a.ablate, o.x4);
       if (rowE || colE) edge_group<VEL, GP>(ea, fb, o, LD, m1, 16 * g1, lane, rowE, colE);
     }
   }
@@ -378,7 +414,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
     double* er = lds + L::EDGE + wv * 15 * 16;
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
-      if ((q < 4 && !VEL) || (q == 4 && !GP)) continue;
+      if ((q == 0 && VEL == 0) || (q >= 1 && q < 4 && VEL != 1) || (q == 4 && !GP)) continue;
       const double x = quad_sum(ea.er[q]), y = quad_sum(ea.ec[q]), z = quad_sum(ea.ek[q]);
       if (lane < 16) { er[q * 16 + lane] = x; er[(5 + q) * 16 + lane] = y; er[(10 + q) * 16 + lane] = z; }
     }
@@ -407,8 +443,10 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   double sums[PS_NSUM] = {0, 0, 0, 0, 0, 0, 0, 0};
   double maxs[2] = {0, 0};
   double un = 0.0, vn = 0.0;
+  double dsum = 0.0;                 // this thread's share of the enstrophy (DIAG 1) / palinstrophy (DIAG 2) sum
   double* tu = lds + L::TILE;
   double* tv = tu + 16 * 17;
+  double* tw = tv + 16 * 17;
 
   if (owner) {
     // ---- pointwise epilogue: thread owns node (i, j) ---------------------------------------------
@@ -424,10 +462,21 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
       lu += d2xl * ue + un_ * d2yl;
       lv += d2xl * ve + vn_ * d2yl;
     }
-    if (GP) {
+    if (GPV) {
       px = valid ? rsum(0, 4) : 0.0;   // row M-1 of T1T/T2T meets a zero column of GxF/IxF: no completion term
       py = valid ? rsum(1, 4) : 0.0;
       if (!DUMP) { a.PX[ij] = px; a.PY[ij] = py; }
+    }
+    if (DIAG == 1) {
+      const double w = valid ? (vx - uy) : 0.0;          // sg.py:510-522 on phi^(n+1) (= this stage's input)
+      a.W[ij] = w;
+      tw[ti * 17 + tj] = w;
+      dsum = valid ? wq * w * w : 0.0;
+    }
+    if (DIAG == 2) {
+      double gx = rsum(0, 4), gy = rsum(1, 4);           // sg.py:546-547
+      if (a.tail) { gx += dxl * we; gy += wn * dyl; }
+      dsum = valid ? wq * (gx * gx + gy * gy) : 0.0;
     }
     const double Ru = -(uin * ux + vin * uy) - px + a.nu * lu;
     const double Rv = -(uin * vx + vin * vy) - py + a.nu * lv;
@@ -474,14 +523,27 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
       const int ej = (kind == 0) ? (c0 + idx) : m1;
       const size_t eij = (size_t)ei * LD + ej;
       // role 0: c00 ux, c01 vx, c10 luX, c11 lvX, c4 px     role 1: c00 uy, c10 vy, c01 luY, c11 lvY, c4 py
-      double epx, epy;
-      if (GP) {
+      double epx = 0.0, epy = 0.0;
+      if (GPV) {
         epx = esum(0, kind, 4, idx); epy = esum(1, kind, 4, idx);
         if (!DUMP) { a.PX[eij] = epx; a.PY[eij] = epy; }
-      } else {
+      } else if (VEL == 1) {
         epx = a.PX[eij]; epy = a.PY[eij];
       }
-      if (VEL) {
+      if (DIAG == 1) {
+        const double vx = esum(0, kind, 0, idx) + a.DxL[ei] * a.Vin[(size_t)m1 * LD + ej];   // slot 0 of role 0
+        const double uy = esum(1, kind, 0, idx) + a.Uin[(size_t)ei * LD + m1] * a.DyL[ej];   // slot 0 of role 1
+        const double w = vx - uy;
+        a.W[eij] = w;
+        a.WT[(size_t)ej * LD + ei] = w;
+        dsum = a.wx[ei] * a.wy[ej] * w * w;
+      }
+      if (DIAG == 2) {
+        const double gx = esum(0, kind, 4, idx) + a.DxL[ei] * a.W[(size_t)m1 * LD + ej];
+        const double gy = esum(1, kind, 4, idx) + a.W[(size_t)ei * LD + m1] * a.DyL[ej];
+        dsum = a.wx[ei] * a.wy[ej] * (gx * gx + gy * gy);
+      }
+      if (VEL == 1) {
         double ux = esum(0, kind, 0, idx), vx = esum(0, kind, 1, idx);
         double lu = esum(0, kind, 2, idx) + esum(1, kind, 1, idx);
         double lv = esum(0, kind, 3, idx) + esum(1, kind, 3, idx);
@@ -520,6 +582,24 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
     const size_t ot = (size_t)(c0 + tr) * LD + r0 + tc;
     a.UoutT[ot] = tu[tc * 17 + tr];
     a.VoutT[ot] = tv[tc * 17 + tr];
+    if (DIAG == 1) a.WT[ot] = tw[tc * 17 + tr];
+  }
+  if (DIAG != 0) {
+    // one partial sum per work-group into the parity slab of the state this stage started from
+    red[tid] = dsum;
+    __syncthreads();
+    if (wv == 0) {
+      double x = 0.0;
+#pragma unroll
+      for (int m = 0; m < kStageWaves; ++m) x += red[lane + 64 * m];
+      x = wave_sum(x);
+      double* slab = (DIAG == 1 ? a.partZ0 : a.partP0) + (size_t)((step0 > 0 ? step0 - 1 : 0) & 1) * a.stride;
+      if (lane == 0) slab[(size_t)blockIdx.x * LDC_NPART] = x;
+    }
+    if (DIAG == 2 && blockIdx.x == 0 && tid == 0) {      // Z and P partials of state `step0` are complete
+      a.ctrl[LDC_CTRL_PDONE] = step0;
+      a.ctrl[LDC_CTRL_DROWS] = (int)gridDim.x;
+    }
   }
   if (LAST) {
     // block reduction through LDS (the accumulator region is free again): one wave per value,
@@ -578,14 +658,17 @@ __device__ __forceinline__ double next_dt(double umax, double vmax, const FinalA
 
 // all kThreads threads of one block call this; sm holds kThreads * (PS_N + 2) doubles
 __device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t) {
-  __shared__ int fin_state[4];       // one reader: the decision below guards barriers
+  __shared__ int fin_state[6];       // one reader: the decision below guards barriers
   if (t == 0) {
     fin_state[0] = a.ctrl[LDC_CTRL_DONE]; fin_state[1] = a.ctrl[LDC_CTRL_ITER];
     fin_state[2] = a.ctrl[LDC_CTRL_STEP]; fin_state[3] = a.ctrl[LDC_CTRL_FLUSHED];
+    fin_state[4] = a.ctrl[LDC_CTRL_PDONE]; fin_state[5] = a.ctrl[LDC_CTRL_DROWS];
   }
   __syncthreads();
   const int done = fin_state[0], iter = fin_state[1], step = fin_state[2], flushed = fin_state[3];
-  const bool flush = a.with_diag && (flushed < iter);             // record iter-1 lacks Z, P
+  const int pdone = fin_state[4], drows = fin_state[5];
+  // record iter-1 lacks Z, P, and the partial sums of state `iter` (its end state) are complete
+  const bool flush = a.with_diag && (flushed < iter) && (pdone >= iter);
   const bool crit = a.do_critical && !done && (step > iter);       // iteration `iter` awaits its record
   if (!flush && !crit) return;
   double v[PS_N + 2];
@@ -604,8 +687,8 @@ __device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t) 
     const int par = (iter - 1) & 1;
     const double* pz = a.partZ0 + (size_t)par * a.stride;
     const double* pp = a.partP0 + (size_t)par * a.stride;
-    for (int r = t; r < a.nblkZ; r += kThreads) v[PS_N] += pz[(size_t)r * LDC_NPART];
-    for (int r = t; r < a.nblkP; r += kThreads) v[PS_N + 1] += pp[(size_t)r * LDC_NPART];
+    for (int r = t; r < drows; r += kThreads) v[PS_N] += pz[(size_t)r * LDC_NPART];
+    for (int r = t; r < drows; r += kThreads) v[PS_N + 1] += pp[(size_t)r * LDC_NPART];
   }
 #pragma unroll
   for (int q = 0; q < PS_N + 2; ++q) sm[q * kThreads + t] = v[q];
@@ -817,7 +900,7 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
 struct PalinArgs {
   int M, LD, T, tail;
   const double *Dx, *Dy, *W, *WT, *wx, *wy;
-  const int* ctrl;
+  int* ctrl;
   double* partP0;
   long long stride;
   int ungated;
@@ -878,6 +961,10 @@ __global__ __launch_bounds__(kThreads) void palin_kernel(const PalinArgs a_val, 
     }
   }
   block_reduce_store<1, 0>(sums, dummy, red, partP + (size_t)b * LDC_NPART, lane, wv);
+  if (b == 0 && tid == 0) {          // Z (post, omega blocks) and P partials of state `step` are complete
+    a.ctrl[LDC_CTRL_PDONE] = step;
+    a.ctrl[LDC_CTRL_DROWS] = (int)gridDim.x;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1075,9 +1162,10 @@ struct ldc_batch {
   StageArgs* d_stage[4];     // device argument arrays, one entry per trial
   PostArgs* d_post[2];       // [with_diagnostics], inside the loop (with finalize block)
   PostArgs* d_postT[2];      // T-only launches on PA / PB (smoother mode)
-  PalinArgs* d_palin;
+  PalinArgs* d_palin;        // stand-alone (closing) form
+  PostArgs* d_post_close;    // stand-alone post with omega blocks
   FinalArgs* d_flush;
-  int post_grid[2], postT_grid;
+  int post_grid[2], postT_grid, post_close_grid;
   int iters_per_graph;
   hipGraphExec_t graph[2];
   hipStream_t capture_stream;
@@ -1107,6 +1195,9 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
   a.ulid = p.ulid; a.wx = p.wx; a.wy = p.wy; a.scal = p.scal; a.ctrl = p.ctrl;
   a.DxL = p.DxL; a.D2xL = p.D2xL; a.DyL = p.DyL; a.D2yL = p.D2yL;
   a.partials = p.partials;
+  a.W = p.W; a.WT = p.WT;
+  a.partZ0 = p.partials + p.partials_stride; a.partP0 = p.partials + 3 * p.partials_stride;
+  a.stride = p.partials_stride;
   a.ablate = s->ablate;
   // ping-pong: 0: S0 -> A, 1: A -> B, 2: B -> A, 3: A -> S0 (in place)
   const double *in[4][4] = {{p.U, p.UT, p.V, p.VT}, {p.UA, p.UAT, p.VA, p.VAT},
@@ -1124,33 +1215,39 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
   return a;
 }
 
-template <bool GP, bool LAST, bool DUMP, bool BATCH>
+template <bool GP, bool LAST, bool DUMP, bool BATCH, int DIAG>
 int launch_stage_kernel(const StageArgs& a, const StageArgs* arr, int nt, int nbatch, hipStream_t st) {
   static bool attr_set = false;   // dynamic LDS above 64 KiB must be enabled once per kernel
-  auto kern = stage_kernel<GP, LAST, DUMP, BATCH>;
+  auto kern = stage_kernel<GP, LAST, DUMP, BATCH, DIAG>;
+  constexpr size_t lds_bytes = StageLds<GP || DIAG == 2>::BYTES;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)StageLds<GP>::BYTES));
+                                (int)lds_bytes));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nt, nbatch), dim3(kStageThreads), StageLds<GP>::BYTES, st, a, arr);
+  hipLaunchKernelGGL(kern, dim3(nt, nbatch), dim3(kStageThreads), lds_bytes, st, a, arr);
   return (int)hipGetLastError();
 }
 
-template <bool GP, bool LAST, bool DUMP>
-int launch_stage_variant(const StageArgs& a, int nt, hipStream_t st) {
-  return launch_stage_kernel<GP, LAST, DUMP, false>(a, nullptr, nt, 1, st);
+// which instantiation runs RK stage k (diag: fuse the omega / palinstrophy work into stages 1 and 2)
+template <bool BATCH>
+int launch_stage_any(const StageArgs& a, const StageArgs* arr, int k, bool stage_pressure, bool diag, int nt,
+                     int nbatch, hipStream_t st) {
+  if (stage_pressure) {   // FSG smoother: every stage differentiates its own input pressure; no diagnostics
+    if (k < 3) return launch_stage_kernel<true, false, false, BATCH, 0>(a, arr, nt, nbatch, st);
+    return launch_stage_kernel<true, true, false, BATCH, 0>(a, arr, nt, nbatch, st);
+  }
+  if (k == 0) return diag ? launch_stage_kernel<true, false, false, BATCH, 1>(a, arr, nt, nbatch, st)
+                          : launch_stage_kernel<true, false, false, BATCH, 0>(a, arr, nt, nbatch, st);
+  if (k == 1) return diag ? launch_stage_kernel<false, false, false, BATCH, 2>(a, arr, nt, nbatch, st)
+                          : launch_stage_kernel<false, false, false, BATCH, 0>(a, arr, nt, nbatch, st);
+  if (k == 2) return launch_stage_kernel<false, false, false, BATCH, 0>(a, arr, nt, nbatch, st);
+  return launch_stage_kernel<false, true, false, BATCH, 0>(a, arr, nt, nbatch, st);
 }
 
-int launch_stage(ldc_solver* s, int k, hipStream_t st) {
+int launch_stage(ldc_solver* s, int k, int diag, hipStream_t st) {
   const StageArgs a = make_stage_args(s, k);
-  if (s->p.stage_pressure) {   // every stage differentiates its own input pressure (T1T/T2T are fresh)
-    if (k < 3) return launch_stage_variant<true, false, false>(a, s->nt, st);
-    return launch_stage_variant<true, true, false>(a, s->nt, st);
-  }
-  if (k == 0) return launch_stage_variant<true, false, false>(a, s->nt, st);
-  if (k < 3) return launch_stage_variant<false, false, false>(a, s->nt, st);
-  return launch_stage_variant<false, true, false>(a, s->nt, st);
+  return launch_stage_any<false>(a, nullptr, k, s->p.stage_pressure != 0, diag != 0, s->nt, 1, st);
 }
 
 FinalArgs make_final_args(const ldc_solver* s, int with_diag, int do_critical) {
@@ -1226,16 +1323,24 @@ int launch_finalize(const ldc_solver* s, int with_diag, int do_critical, hipStre
 int launch_iteration(ldc_solver* s, int with_diag, hipStream_t st) {
   int e;
   for (int k = 0; k < 4; ++k) {
-    if ((e = launch_stage(s, k, st)) != 0) return e;
+    if ((e = launch_stage(s, k, with_diag, st)) != 0) return e;
     if (s->p.stage_pressure && k < 3) {
       // transforms of the stage pressure just produced (PA, PB, PA) for the next stage
       const double* pk = (k == 1) ? s->p.PB : s->p.PA;
       if ((e = launch_post(s, pk, 0, 0, 0, st)) != 0) return e;
     }
   }
-  if ((e = launch_post(s, s->p.P, with_diag, 1, with_diag, st)) != 0) return e;
-  if (with_diag && (e = launch_palin(s, 1, st)) != 0) return e;
-  return 0;
+  // omega / Z / P of the new state ride along in stages 1 and 2 of the NEXT iteration
+  return launch_post(s, s->p.P, 0, 1, with_diag, st);
+}
+
+// close the last record of an enqueue: nothing follows that would carry its omega / Z / P, so compute them
+// stand-alone (ungated, idempotent), then fold
+int launch_closing_diagnostics(ldc_solver* s, hipStream_t st) {
+  int e;
+  if ((e = launch_post(s, s->p.P, 1, 0, 0, st)) != 0) return e;
+  if ((e = launch_palin(s, 0, st)) != 0) return e;
+  return launch_finalize(s, 1, 0, st);
 }
 
 int build_graph(ldc_solver* s, int with_diag) {
@@ -1254,30 +1359,22 @@ int build_graph(ldc_solver* s, int with_diag) {
 
 size_t batch_bytes(int B) {
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
-  return 4 * up(sizeof(StageArgs) * B) + 4 * up(sizeof(PostArgs) * B) + up(sizeof(PalinArgs) * B) +
+  return 4 * up(sizeof(StageArgs) * B) + 5 * up(sizeof(PostArgs) * B) + up(sizeof(PalinArgs) * B) +
          up(sizeof(FinalArgs) * B);
 }
 
-int batch_launch_stage(ldc_batch* b, int k, hipStream_t st) {
+int batch_launch_stage(ldc_batch* b, int k, int diag, hipStream_t st) {
   const ldc_solver* s0 = b->s[0];
   const StageArgs dummy = {};
-  const bool sp = s0->p.stage_pressure != 0;
-  if (sp) {
-    if (k < 3) return launch_stage_kernel<true, false, false, true>(dummy, b->d_stage[k], s0->nt, b->B, st);
-    return launch_stage_kernel<true, true, false, true>(dummy, b->d_stage[k], s0->nt, b->B, st);
-  }
-  if (k == 0) return launch_stage_kernel<true, false, false, true>(dummy, b->d_stage[k], s0->nt, b->B, st);
-  if (k < 3) return launch_stage_kernel<false, false, false, true>(dummy, b->d_stage[k], s0->nt, b->B, st);
-  return launch_stage_kernel<false, true, false, true>(dummy, b->d_stage[k], s0->nt, b->B, st);
+  return launch_stage_any<true>(dummy, b->d_stage[k], k, s0->p.stage_pressure != 0, diag != 0, s0->nt, b->B, st);
 }
 
 int batch_launch_iteration(ldc_batch* b, int with_diag, hipStream_t st) {
   const ldc_solver* s0 = b->s[0];
   const PostArgs pdummy = {};
-  const PalinArgs qdummy = {};
   int e;
   for (int k = 0; k < 4; ++k) {
-    if ((e = batch_launch_stage(b, k, st)) != 0) return e;
+    if ((e = batch_launch_stage(b, k, with_diag, st)) != 0) return e;
     if (s0->p.stage_pressure && k < 3) {
       hipLaunchKernelGGL(post_kernel<true>, dim3(b->postT_grid, b->B), dim3(kThreads), 0, st, pdummy,
                          (const PostArgs*)b->d_postT[k == 1 ? 1 : 0]);
@@ -1286,13 +1383,23 @@ int batch_launch_iteration(ldc_batch* b, int with_diag, hipStream_t st) {
   }
   hipLaunchKernelGGL(post_kernel<true>, dim3(b->post_grid[with_diag], b->B), dim3(kThreads), 0, st, pdummy,
                      (const PostArgs*)b->d_post[with_diag]);
+  return (int)hipGetLastError();
+}
+
+int batch_closing_diagnostics(ldc_batch* b, hipStream_t st) {
+  const ldc_solver* s0 = b->s[0];
+  const PostArgs pdummy = {};
+  const PalinArgs qdummy = {};
+  const FinalArgs fdummy = {};
+  int e;
+  hipLaunchKernelGGL(post_kernel<true>, dim3(b->post_close_grid, b->B), dim3(kThreads), 0, st, pdummy,
+                     (const PostArgs*)b->d_post_close);
   if ((e = (int)hipGetLastError()) != 0) return e;
-  if (with_diag) {
-    hipLaunchKernelGGL(palin_kernel<true>, dim3(s0->nt + s0->n_edge_blocks, b->B), dim3(kThreads), 0, st, qdummy,
-                       (const PalinArgs*)b->d_palin);
-    if ((e = (int)hipGetLastError()) != 0) return e;
-  }
-  return 0;
+  hipLaunchKernelGGL(palin_kernel<true>, dim3(s0->nt + s0->n_edge_blocks, b->B), dim3(kThreads), 0, st, qdummy,
+                     (const PalinArgs*)b->d_palin);
+  if ((e = (int)hipGetLastError()) != 0) return e;
+  hipLaunchKernelGGL(finalize_kernel<true>, dim3(1, b->B), dim3(kThreads), 0, st, fdummy, (const FinalArgs*)b->d_flush);
+  return (int)hipGetLastError();
 }
 
 int batch_build_graph(ldc_batch* b, int with_diag) {
@@ -1388,8 +1495,10 @@ int ldc_debug_ablate(ldc_solver* s, int mask) {
 
 int ldc_stage(ldc_solver* s, int k, void* stream) {
   if (!s) return LDC_E_STATE;
+  const int diag = (k & 16) ? 1 : 0;     // bit 4: the variant that also carries the fused diagnostics
+  k &= 15;
   if (k < 0 || k > 3) return LDC_E_ARG;
-  return launch_stage(s, k, as_stream(stream));
+  return launch_stage(s, k, diag, as_stream(stream));
 }
 
 int ldc_pressure_transform(ldc_solver* s, int which, void* stream) {
@@ -1451,8 +1560,7 @@ int ldc_solver_enqueue(ldc_solver* s, int n_iters, int with_diag, void* stream) 
     }
   }
   for (; left > 0; --left) { int e = launch_iteration(s, with_diag, st); if (e) return e; }
-  // close the last record (idempotent: folds Z/P only if a record is still open)
-  return with_diag ? launch_finalize(s, 1, 0, st) : 0;
+  return (with_diag && n_iters > 0) ? launch_closing_diagnostics(s, st) : 0;
 }
 
 size_t ldc_batch_workspace_bytes(int n_trials) { return n_trials > 0 ? batch_bytes(n_trials) : 0; }
@@ -1490,7 +1598,7 @@ int ldc_batch_create(ldc_solver* const* solvers, int n_trials, void* workspace, 
   }
   for (int wd = 0; wd < 2; ++wd) {
     std::vector<PostArgs> h(n_trials);
-    for (int q = 0; q < n_trials; ++q) h[q] = make_post_args(solvers[q], solvers[q]->p.P, wd, 1, wd, &b->post_grid[wd]);
+    for (int q = 0; q < n_trials; ++q) h[q] = make_post_args(solvers[q], solvers[q]->p.P, 0, 1, wd, &b->post_grid[wd]);
     b->d_post[wd] = reinterpret_cast<PostArgs*>(carve(sizeof(PostArgs) * n_trials));
     put(b->d_post[wd], h.data(), sizeof(PostArgs) * n_trials);
   }
@@ -1502,8 +1610,12 @@ int ldc_batch_create(ldc_solver* const* solvers, int n_trials, void* workspace, 
     put(b->d_postT[ab], h.data(), sizeof(PostArgs) * n_trials);
   }
   {
+    std::vector<PostArgs> hc(n_trials);
+    for (int q = 0; q < n_trials; ++q) hc[q] = make_post_args(solvers[q], solvers[q]->p.P, 1, 0, 0, &b->post_close_grid);
+    b->d_post_close = reinterpret_cast<PostArgs*>(carve(sizeof(PostArgs) * n_trials));
+    put(b->d_post_close, hc.data(), sizeof(PostArgs) * n_trials);
     std::vector<PalinArgs> h(n_trials);
-    for (int q = 0; q < n_trials; ++q) h[q] = make_palin_args(solvers[q], 1);
+    for (int q = 0; q < n_trials; ++q) h[q] = make_palin_args(solvers[q], 0);
     b->d_palin = reinterpret_cast<PalinArgs*>(carve(sizeof(PalinArgs) * n_trials));
     put(b->d_palin, h.data(), sizeof(PalinArgs) * n_trials);
     std::vector<FinalArgs> f(n_trials);
@@ -1538,12 +1650,7 @@ int ldc_batch_enqueue(ldc_batch* b, int n_iters, int with_diag, void* stream) {
     }
   }
   for (; left > 0; --left) { int e = batch_launch_iteration(b, with_diag, st); if (e) return e; }
-  if (with_diag) {
-    const FinalArgs fdummy = {};
-    hipLaunchKernelGGL(finalize_kernel<true>, dim3(1, b->B), dim3(kThreads), 0, st, fdummy, (const FinalArgs*)b->d_flush);
-    return (int)hipGetLastError();
-  }
-  return 0;
+  return (with_diag && n_iters > 0) ? batch_closing_diagnostics(b, st) : 0;
 }
 
 int ldc_residual_debug(ldc_solver* s, int which, double* const out[11], void* stream) {
@@ -1555,7 +1662,7 @@ int ldc_residual_debug(ldc_solver* s, int which, double* const out[11], void* st
   if (e) return e;
   StageArgs a = make_stage_args(s, which == 0 ? 0 : which == 1 ? 1 : 2);
   for (int q = 0; q < 11; ++q) a.dump[q] = out[q];
-  return launch_stage_variant<true, false, true>(a, s->nt, st);
+  return launch_stage_kernel<true, false, true, false, 0>(a, nullptr, s->nt, 1, st);
 }
 
 int ldc_gemm_nt(const double* A, const double* B, double* C, int R16, int K16, int LD, int transpose_out,

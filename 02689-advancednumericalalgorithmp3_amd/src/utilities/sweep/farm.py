@@ -160,7 +160,10 @@ class TPESampler:
             for k, dom in self.space.items():
                 if isinstance(dom, self.Interval):
                     width = dom.high - dom.low
-                    cand[k] = float(np.clip(base[k] + self.rng.normal(0.0, width / 6.0), dom.low, dom.high))
+                    x = base[k] + self.rng.normal(0.0, width / 6.0)
+                    while x < dom.low or x > dom.high:          # reflect at the bounds (clipping piles up there)
+                        x = 2 * dom.low - x if x < dom.low else 2 * dom.high - x
+                    cand[k] = float(x)
                 else:
                     cand[k] = base[k] if self.rng.random() < 0.7 else dom[int(self.rng.integers(len(dom)))]
             sc = self._score(cand, good) - self._score(cand, bad)

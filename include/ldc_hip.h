@@ -56,6 +56,8 @@ enum {
   LDC_CTRL_ITER      = 1, /* iterations finalized (records written)                     */
   LDC_CTRL_STEP      = 2, /* stage-4 state updates completed                            */
   LDC_CTRL_FLUSHED   = 3, /* records whose Z/P slots have been folded                   */
+  LDC_CTRL_PDONE     = 4, /* state index whose Z/P partial sums are complete            */
+  LDC_CTRL_DROWS     = 5, /* rows of those partial-sum slabs                            */
   LDC_CTRL_LEN       = 8
 };
 
@@ -125,6 +127,7 @@ int ldc_solver_destroy(ldc_solver *s);
 
 /* one RK stage (k = 0..3) of SGSolver.step: residual + update + BCs fused               */
 /* replaces sg.py:434-447 (_compute_residuals :278-346, axpy :438-446, BCs :348-385)     */
+/* k | 16 launches the variant that also carries the fused diagnostics (stages 0 and 1 only)   */
 int ldc_stage(ldc_solver *s, int k, void *stream);
 /* T1T/T2T from the current pressure (first half of _interpolate_pressure_gradient,     */
 /* sg.py:270); `which` 0: P, 1: PA, 2: PB                                                */

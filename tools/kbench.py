@@ -51,6 +51,8 @@ rows = [("stage0 (GP)", lambda: lib.ldc_stage(h, 0, st), 20 * M**3),
         ("stage1", lambda: lib.ldc_stage(h, 1, st), 16 * M**3),
         ("stage2", lambda: lib.ldc_stage(h, 2, st), 16 * M**3),
         ("stage3 (LAST)", lambda: lib.ldc_stage(h, 3, st), 16 * M**3),
+        ("stage0 (GP) + omega", lambda: lib.ldc_stage(h, 16, st), 20 * M**3),
+        ("stage1 + grad omega", lambda: lib.ldc_stage(h, 17, st), 20 * M**3),
         ("ptrans", lambda: lib.ldc_pressure_transform(h, 0, st), 4 * M**3),
         ("diagnostics (post+omega, palin)", lambda: lib.ldc_diagnostics(h, st), 12 * M**3),
         ("finalize", lambda: lib.ldc_finalize(h, 1, st), 0)]
@@ -61,7 +63,7 @@ for name, fn, fl in rows:
     print(f"{name:34s} median {med:8.2f} us  best {best:8.2f} us  {tf:6.2f} TFLOP/s")
 for mask, label in ((1, "no MFMA"), (2, "no operand loads"), (3, "neither")):
     lib.ldc_debug_ablate(h, mask)
-    for name, fn, fl in rows[:4]:
+    for name, fn, fl in rows[:6]:
         med, best = burst(fn)
         print(f"  ablate[{label:16s}] {name:16s} median {med:8.2f} us")
 lib.ldc_debug_ablate(h, 0)
