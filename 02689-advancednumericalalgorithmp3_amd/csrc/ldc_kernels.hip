@@ -175,31 +175,38 @@ struct RoleOps {
   int x4;   // fifth contraction: 0: A2.B2 (grad p)   1: A0.B2 (d omega/dx = Dx . WT)   2: A2.B0 (d omega/dy = W . Dy)
 };
 
-template <bool GP>
-struct RoleFrags {
-  v4d a0, a1, b0, b1, a2, b2;
+struct RoleFrags {     // the four operands of the 2x2 combination, double-buffered by the caller
+  v4d a0, a1, b0, b1;
+};
+struct ExtraFrags {    // operands of the fifth contraction: single-buffered (loaded at the top of a group,
+  v4d a2, b2;          // consumed by that group's LAST four MFMAs, ~1600 cycles later)
 };
 
-template <bool GP>
-__device__ __forceinline__ void load_role(RoleFrags<GP>& f, const RoleOps& o, int LD, int r0, int c0, int k0, int lane) {
+__device__ __forceinline__ void load_role(RoleFrags& f, const RoleOps& o, int LD, int r0, int c0, int k0, int lane) {
   if (o.ablate & 2) {
     const double x = 1e-3 * lane + k0;
-    f.a0 = (v4d){x, x, x, x}; f.a1 = f.a0; f.b0 = f.a0; f.b1 = f.a0; f.a2 = f.a0; f.b2 = f.a0;
+    f.a0 = (v4d){x, x, x, x}; f.a1 = f.a0; f.b0 = f.a0; f.b1 = f.a0;
     return;
   }
   f.a0 = ldfrag(o.A0, LD, r0, k0, lane); f.a1 = ldfrag(o.A1, LD, r0, k0, lane);
   f.b0 = ldfrag(o.B0, LD, c0, k0, lane); f.b1 = ldfrag(o.B1, LD, c0, k0, lane);
-  if (GP) {   // GP here means "has a fifth contraction"
-    if (o.x4 != 1) f.a2 = ldfrag(o.A2, LD, r0, k0, lane);
-    if (o.x4 != 2) f.b2 = ldfrag(o.B2, LD, c0, k0, lane);
+}
+
+__device__ __forceinline__ void load_extra(ExtraFrags& x, const RoleOps& o, int LD, int r0, int c0, int k0, int lane) {
+  if (o.ablate & 2) {
+    const double y = 2e-3 * lane + k0;
+    x.a2 = (v4d){y, y, y, y}; x.b2 = x.a2;
+    return;
   }
+  if (o.x4 != 1) x.a2 = ldfrag(o.A2, LD, r0, k0, lane);
+  if (o.x4 != 2) x.b2 = ldfrag(o.B2, LD, c0, k0, lane);
 }
 
 template <bool GP, int NA>
-__device__ __forceinline__ void mfma_role(const RoleFrags<GP>& f, v4d (&acc)[NA], int ablate, int x4) {
+__device__ __forceinline__ void mfma_role(const RoleFrags& f, const ExtraFrags& x, v4d (&acc)[NA], int ablate, int x4) {
   if (ablate & 1) {   // keep the operands live without issuing MFMAs
     acc[0][0] += f.a0[0] + f.b0[1] + f.a1[2] + f.b1[3];
-    if (GP) acc[4][0] += f.a2[0] + f.b2[0];
+    if (GP) acc[4][0] += x.a2[0] + x.b2[0];
     return;
   }
 #pragma unroll
@@ -208,10 +215,13 @@ __device__ __forceinline__ void mfma_role(const RoleFrags<GP>& f, v4d (&acc)[NA]
     acc[1] = MFMA_F64(f.a0[s], f.b1[s], acc[1]);
     acc[2] = MFMA_F64(f.a1[s], f.b0[s], acc[2]);
     acc[3] = MFMA_F64(f.a1[s], f.b1[s], acc[3]);
-    if (GP) {
-      const double x = (x4 == 1) ? f.a0[s] : f.a2[s];
-      const double y = (x4 == 2) ? f.b0[s] : f.b2[s];
-      acc[4] = MFMA_F64(x, y, acc[4]);
+  }
+  if (GP) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const double p = (x4 == 1) ? f.a0[s] : x.a2[s];
+      const double q = (x4 == 2) ? f.b0[s] : x.b2[s];
+      acc[4] = MFMA_F64(p, q, acc[4]);
     }
   }
 }
@@ -232,8 +242,8 @@ struct EdgeAcc {
 //          role 0: A0.B1 = Dx . VT (dv/dx)      role 1: A0.B0 = U . Dy (du/dy)
 // GP : the fifth contraction (grad p, or grad omega by o.x4)
 template <int VEL, bool GP>
-__device__ __forceinline__ void edge_group(EdgeAcc& e, const RoleFrags<GP>& f, const RoleOps& o, int LD, int m1,
-                                           int k0, int lane, bool rowE, bool colE) {
+__device__ __forceinline__ void edge_group(EdgeAcc& e, const RoleFrags& f, const ExtraFrags& x, const RoleOps& o, int LD,
+                                           int m1, int k0, int lane, bool rowE, bool colE) {
   const size_t off = (size_t)m1 * LD + k0 + 4 * (lane >> 4);
   auto row_of = [&](const double* X) { return *reinterpret_cast<const v4d*>(X + off); };
   v4d ar0, ar1, xr, bc0, bc1, yc;
@@ -250,7 +260,7 @@ __device__ __forceinline__ void edge_group(EdgeAcc& e, const RoleFrags<GP>& f, c
     if (VEL == 2) e.er[0] += dot4(ar0, o.role == 0 ? f.b1 : f.b0);
     if (GP) {
       xr = (o.x4 == 1) ? ar0 : row_of(o.A2);
-      e.er[4] += dot4(xr, (o.x4 == 2) ? f.b0 : f.b2);
+      e.er[4] += dot4(xr, (o.x4 == 2) ? f.b0 : x.b2);
     }
   }
   if (colE) {
@@ -263,7 +273,7 @@ __device__ __forceinline__ void edge_group(EdgeAcc& e, const RoleFrags<GP>& f, c
     if (VEL == 2) e.ec[0] += dot4(f.a0, o.role == 0 ? bc1 : bc0);
     if (GP) {
       yc = (o.x4 == 2) ? bc0 : row_of(o.B2);
-      e.ec[4] += dot4((o.x4 == 1) ? f.a0 : f.a2, yc);
+      e.ec[4] += dot4((o.x4 == 1) ? f.a0 : x.a2, yc);
     }
   }
   if (rowE && colE) {
@@ -356,8 +366,9 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
 
   // ---- first fragments in flight before anything else ------------------------------------
   int g = kq;
-  RoleFrags<GP> fa, fb;
-  load_role<GP>(fa, o, LD, r0, c0, 16 * (g < T ? g : 0), lane);
+  RoleFrags fa, fb;
+  ExtraFrags fx;
+  load_role(fa, o, LD, r0, c0, 16 * (g < T ? g : 0), lane);
 
   // the latch and dt are read only now, behind the first operand loads (reads are harmless)
   if (!DUMP && a.ctrl[LDC_CTRL_DONE] != 0) return;
@@ -395,13 +406,15 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   for (int q = 0; q < 5; ++q) { ea.er[q] = 0.0; ea.ec[q] = 0.0; ea.ek[q] = 0.0; }
   for (; g < T; g += 2 * 4) {
     const int g1 = g + 4, g2 = g + 8;
-    load_role<GP>(fb, o, LD, r0, c0, 16 * (g1 < T ? g1 : g), lane);   // clamped: harmless reload
-    mfma_role<GP, NA>(fa, acc, a.ablate, o.x4);
-    if (rowE || colE) edge_group<VEL, GP>(ea, fa, o, LD, m1, 16 * g, lane, rowE, colE);
+    if (GP) load_extra(fx, o, LD, r0, c0, 16 * g, lane);          // first: loads return in issue order
+    load_role(fb, o, LD, r0, c0, 16 * (g1 < T ? g1 : g), lane);   // clamped: harmless reload
+    mfma_role<GP, NA>(fa, fx, acc, a.ablate, o.x4);
+    if (rowE || colE) edge_group<VEL, GP>(ea, fa, fx, o, LD, m1, 16 * g, lane, rowE, colE);
     if (g1 < T) {
-      load_role<GP>(fa, o, LD, r0, c0, 16 * (g2 < T ? g2 : g1), lane);
-      mfma_role<GP, NA>(fb, acc, a.ablate, o.x4);
-      if (rowE || colE) edge_group<VEL, GP>(ea, fb, o, LD, m1, 16 * g1, lane, rowE, colE);
+      if (GP) load_extra(fx, o, LD, r0, c0, 16 * g1, lane);
+      load_role(fa, o, LD, r0, c0, 16 * (g2 < T ? g2 : g1), lane);
+      mfma_role<GP, NA>(fb, fx, acc, a.ablate, o.x4);
+      if (rowE || colE) edge_group<VEL, GP>(ea, fb, fx, o, LD, m1, 16 * g1, lane, rowE, colE);
     }
   }
 
