@@ -375,18 +375,23 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   const int step0 = a.ctrl[LDC_CTRL_STEP];
   const double adt = a.alpha * a.scal[LDC_SCAL_DT];
 
-  // ---- pointwise operands of the epilogue (threads 0..255 own one node each) -----------------
+  // ---- pointwise operands of the epilogue, issued now so that they land under the MFMAs ----------
+  // threads 0..255 own node (i, j) of the tile; in tiles of the last tile row / column threads 256..
+  // own the nodes of index M-1 next to it (kind 0: (M-1, c0+idx), 1: (r0+idx, M-1), 2: the corner)
   const int ti = 4 * (wv & 3) + (lane >> 4), tj = lane & 15;
-  const int i = r0 + ti, j = c0 + tj;
-  const size_t ij = (size_t)i * LD + j;
   const bool owner = tid < 256;
+  const int ekind = (tid - 256) >> 4, eidx = (tid - 256) & 15;
+  const bool edge_thr = !owner && ((ekind == 0 && rowE) || (ekind == 1 && colE) || (ekind == 2 && eidx == 0 && rowE && colE));
+  const int i = owner ? (r0 + ti) : ((ekind == 1) ? (r0 + eidx) : m1);
+  const int j = owner ? (c0 + tj) : ((ekind == 0) ? (c0 + eidx) : m1);
+  const size_t ij = (size_t)i * LD + j;
   double uin = 0, vin = 0, u0 = 0, v0 = 0, p0 = 0, px = 0, py = 0;
   double dxl = 0, d2xl = 0, dyl = 0, d2yl = 0, ue = 0, ve = 0, un_ = 0, vn_ = 0, lidv = 0, wq = 0, we = 0, wn = 0;
-  if (owner) {
+  if (owner || edge_thr) {
     uin = a.Uin[ij]; vin = a.Vin[ij];
     if (!DUMP) { u0 = a.U0[ij]; v0 = a.V0[ij]; }
-    if (!DUMP && a.Pout != nullptr) p0 = a.P0[ij];
-    if (!GPV) { px = a.PX[ij]; py = a.PY[ij]; }
+    if (owner && !DUMP && a.Pout != nullptr) p0 = a.P0[ij];
+    if (!GPV && (owner || VEL == 1)) { px = a.PX[ij]; py = a.PY[ij]; }
     if (a.tail) {
       dxl = a.DxL[i]; d2xl = a.D2xL[i]; dyl = a.DyL[j]; d2yl = a.D2yL[j];
       ue = a.Uin[(size_t)m1 * LD + j]; ve = a.Vin[(size_t)m1 * LD + j];    // east-wall row
@@ -461,13 +466,21 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   double* tv = tu + 16 * 17;
   double* tw = tv + 16 * 17;
 
-  if (owner) {
-    // ---- pointwise epilogue: thread owns node (i, j) ---------------------------------------------
+  if (owner || edge_thr) {
+    // ---- one code path for tile nodes and for the nodes of index M-1 ------------------------------
+    // role 0: c0 du/dx, c1 dv/dx, c2 d2u/dx2, c3 d2v/dx2, c4 dp/dx | d(omega)/dx
+    // role 1: c0 du/dy, c2 dv/dy, c1 d2u/dy2, c3 d2v/dy2, c4 dp/dy | d(omega)/dy
+    auto C = [&](int rl, int q) { return owner ? rsum(rl, q) : esum(rl, ekind, q, eidx); };
     const bool valid = (i < M) && (j < M);
     const bool interior = (i >= 1) && (i <= M - 2) && (j >= 1) && (j <= M - 2);
-    double ux = rsum(0, 0), vx = rsum(0, 1), lu = rsum(0, 2), lv = rsum(0, 3);
-    double uy = rsum(1, 0), vy = rsum(1, 2);
-    lu += rsum(1, 1); lv += rsum(1, 3);
+    const bool full = owner || VEL == 1;      // all four velocity contractions are available here
+    double ux = 0, vx = 0, uy = 0, vy = 0, lu = 0, lv = 0;
+    if (full) {
+      ux = C(0, 0); vx = C(0, 1); lu = C(0, 2) + C(1, 1); lv = C(0, 3) + C(1, 3);
+      uy = C(1, 0); vy = C(1, 2);
+    } else if (VEL == 2) {                     // edge node in stage 1: slot 0 holds what omega needs
+      vx = C(0, 0); uy = C(1, 0);
+    }
     if (a.tail) {
       // k = M-1 lies outside the MFMA range: exact rank-1 completion of every contraction
       ux += dxl * ue; vx += dxl * ve;
@@ -476,18 +489,18 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
       lv += d2xl * ve + vn_ * d2yl;
     }
     if (GPV) {
-      px = valid ? rsum(0, 4) : 0.0;   // row M-1 of T1T/T2T meets a zero column of GxF/IxF: no completion term
-      py = valid ? rsum(1, 4) : 0.0;
+      px = valid ? C(0, 4) : 0.0;   // row M-1 of T1T/T2T meets a zero column of GxF/IxF: no completion term
+      py = valid ? C(1, 4) : 0.0;
       if (!DUMP) { a.PX[ij] = px; a.PY[ij] = py; }
     }
     if (DIAG == 1) {
       const double w = valid ? (vx - uy) : 0.0;          // sg.py:510-522 on phi^(n+1) (= this stage's input)
       a.W[ij] = w;
-      tw[ti * 17 + tj] = w;
+      if (owner) tw[ti * 17 + tj] = w; else a.WT[(size_t)j * LD + i] = w;
       dsum = valid ? wq * w * w : 0.0;
     }
     if (DIAG == 2) {
-      double gx = rsum(0, 4), gy = rsum(1, 4);           // sg.py:546-547
+      double gx = C(0, 4), gy = C(1, 4);                 // sg.py:546-547
       if (a.tail) { gx += dxl * we; gy += wn * dyl; }
       dsum = valid ? wq * (gx * gx + gy * gy) : 0.0;
     }
@@ -501,7 +514,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
         a.dump[8][ij] = Ru; a.dump[9][ij] = Rv;
         if (interior) a.dump[10][ij] = Rp;
       }
-    } else {
+    } else if (owner) {
       un = u0 + adt * Ru; vn = v0 + adt * Rv;
       // walls first, lid last (sg.py:348-385): the lid row wins the two top corners
       if (!valid) { un = 0.0; vn = 0.0; }
@@ -525,66 +538,12 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
         maxs[0] = fabs(un);
         maxs[1] = fabs(vn);
       }
-    }
-  } else if (rowE || colE) {
-    // ---- nodes of index M-1 handled by this tile: threads 256.. finish them ------------------------
-    const int t = tid - 256;
-    const int kind = t >> 4, idx = t & 15;           // 0: (M-1, c0+idx)   1: (r0+idx, M-1)   2: corner
-    const bool act = (kind == 0 && rowE) || (kind == 1 && colE) || (kind == 2 && idx == 0 && rowE && colE);
-    if (kind < 3 && act) {
-      const int ei = (kind == 1) ? (r0 + idx) : m1;
-      const int ej = (kind == 0) ? (c0 + idx) : m1;
-      const size_t eij = (size_t)ei * LD + ej;
-      // role 0: c00 ux, c01 vx, c10 luX, c11 lvX, c4 px     role 1: c00 uy, c10 vy, c01 luY, c11 lvY, c4 py
-      double epx = 0.0, epy = 0.0;
-      if (GPV) {
-        epx = esum(0, kind, 4, idx); epy = esum(1, kind, 4, idx);
-        if (!DUMP) { a.PX[eij] = epx; a.PY[eij] = epy; }
-      } else if (VEL == 1) {
-        epx = a.PX[eij]; epy = a.PY[eij];
-      }
-      if (DIAG == 1) {
-        const double vx = esum(0, kind, 0, idx) + a.DxL[ei] * a.Vin[(size_t)m1 * LD + ej];   // slot 0 of role 0
-        const double uy = esum(1, kind, 0, idx) + a.Uin[(size_t)ei * LD + m1] * a.DyL[ej];   // slot 0 of role 1
-        const double w = vx - uy;
-        a.W[eij] = w;
-        a.WT[(size_t)ej * LD + ei] = w;
-        dsum = a.wx[ei] * a.wy[ej] * w * w;
-      }
-      if (DIAG == 2) {
-        const double gx = esum(0, kind, 4, idx) + a.DxL[ei] * a.W[(size_t)m1 * LD + ej];
-        const double gy = esum(1, kind, 4, idx) + a.W[(size_t)ei * LD + m1] * a.DyL[ej];
-        dsum = a.wx[ei] * a.wy[ej] * (gx * gx + gy * gy);
-      }
-      if (VEL == 1) {
-        double ux = esum(0, kind, 0, idx), vx = esum(0, kind, 1, idx);
-        double lu = esum(0, kind, 2, idx) + esum(1, kind, 1, idx);
-        double lv = esum(0, kind, 3, idx) + esum(1, kind, 3, idx);
-        double uy = esum(1, kind, 0, idx), vy = esum(1, kind, 2, idx);
-        {  // rank-1 completion, k = M-1
-          const double exl = a.DxL[ei], e2xl = a.D2xL[ei], eyl = a.DyL[ej], e2yl = a.D2yL[ej];
-          const double ee = a.Uin[(size_t)m1 * LD + ej], fe = a.Vin[(size_t)m1 * LD + ej];
-          const double en = a.Uin[(size_t)ei * LD + m1], fn = a.Vin[(size_t)ei * LD + m1];
-          ux += exl * ee; vx += exl * fe;
-          uy += en * eyl; vy += fn * eyl;
-          lu += e2xl * ee + en * e2yl;
-          lv += e2xl * fe + fn * e2yl;
-        }
-        const double eu = a.Uin[eij], ev = a.Vin[eij];
-        const double Ru = -(eu * ux + ev * uy) - epx + a.nu * lu;
-        const double Rv = -(eu * vx + ev * vy) - epy + a.nu * lv;
-        if (DUMP) {
-          a.dump[0][eij] = ux; a.dump[1][eij] = uy; a.dump[2][eij] = vx; a.dump[3][eij] = vy;
-          a.dump[4][eij] = lu; a.dump[5][eij] = lv; a.dump[6][eij] = epx; a.dump[7][eij] = epy;
-          a.dump[8][eij] = Ru; a.dump[9][eij] = Rv;
-        } else if (LAST) {
-          const double b0 = a.U0[eij], c0v = a.V0[eij];   // boundary values never change
-          sums[PS_U02] = b0 * b0; sums[PS_V02] = c0v * c0v;
-          sums[PS_RU2] = Ru * Ru; sums[PS_RV2] = Rv * Rv;
-          sums[PS_E] = a.wx[ei] * a.wy[ej] * (b0 * b0 + c0v * c0v);
-          maxs[0] = fabs(b0); maxs[1] = fabs(c0v);
-        }
-      }
+    } else if (LAST) {
+      // node of index M-1: its value is a boundary condition and never changes
+      sums[PS_U02] = u0 * u0; sums[PS_V02] = v0 * v0;
+      sums[PS_RU2] = Ru * Ru; sums[PS_RV2] = Rv * Rv;
+      sums[PS_E] = wq * (u0 * u0 + v0 * v0);
+      maxs[0] = fabs(u0); maxs[1] = fabs(v0);
     }
   }
   if (DUMP) return;
