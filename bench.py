@@ -173,6 +173,19 @@ def cpu_baseline(N, Re, budget_s=14.0):
                        f"(best of {cands}; {cap} CPUs available)")
 
 
+def pmc_traffic(N):
+    """HBM/fabric bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r*_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of tools/pmc_run.py at
+    N=256, gfx950 correction applied as MI355X_MICROARCH.md prescribes).  None for other sizes."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if N != 256 or not files:
+        return None, None
+    with open(files[-1]) as f:
+        k = json.load(f)["kernels"].get("stage_kernel<false, false, false, false, 0>")
+    return (k["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)) if k else (None, None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +233,7 @@ def main():
         f_launch = 16.0 * M**3          # 8 contractions x 2 M^3 (stage 1 adds 4 M^3 for grad p)
         achieved = f_launch / t_stage / 1e12
         peak_meas = mfma_peak_measured()
+        traffic, traffic_src = pmc_traffic(a.N)
         out = {
             "metric": "steady-state time-steps/sec at N=256 Re=1000",
             "value": world * a.steps / wall, "unit": "steps/s", "n_gpus": world, "steps": a.steps,
@@ -234,7 +248,8 @@ def main():
             "iteration_tflops": flops_per_step(a.N, True) * a.steps / wall / 1e12,
             "roofline": {"bound": "mfma", "kernel": "stage_kernel<GP=0,LAST=0,DUMP=0> (fused RK stage)", "achieved": achieved,
                          "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
-                         "traffic": None, "flops_per_launch": f_launch, "launch_us": t_stage * 1e6,
+                         "traffic": traffic, "traffic_unit": "bytes/launch (FETCH_SIZE+WRITE_SIZE)",
+                         "traffic_source": traffic_src, "flops_per_launch": f_launch, "launch_us": t_stage * 1e6,
                          "peak_measured": peak_meas, "frac_of_measured": achieved / peak_meas},
         }
         if world == 1 and not a.no_cpu:

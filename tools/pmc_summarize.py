@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Fold the rocprofv3 --pmc passes of tools/pmc_run.py into one JSON (profiles/rNN_*_pmc.json).
+
+    rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d gpurun_out/pmc_TCC_HIT  -o run --output-format csv -- python3 tools/pmc_run.py
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE               -d gpurun_out/pmc_FETCH_SIZE ...
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE               -d gpurun_out/pmc_WRITE_SIZE ...
+    python tools/pmc_summarize.py gpurun_out/pmc_TCC_HIT gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > profiles/r01_v3_pmc.json
+
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts the wide (128 B) reads at half size, so it is
+doubled (MI355X_MICROARCH.md, HBM / rocprofv3 section).  Means are per launch of each library kernel."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+KEEP = ("stage_kernel", "post_kernel", "palin_kernel", "finalize_kernel", "prime_kernel")
+
+
+def short(name):
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    return name.split("(")[0].strip()
+
+
+def main(dirs):
+    acc = defaultdict(lambda: defaultdict(list))
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f, newline="") as fh:
+                for r in csv.DictReader(fh):
+                    k = short(r["Kernel_Name"])
+                    if not k.startswith(KEEP):
+                        continue
+                    acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    acc[k]["dur_us_" + r["Counter_Name"]].append(
+                        (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    out = {}
+    for k, cs in acc.items():
+        e = {c: sum(v) / len(v) for c, v in cs.items()}
+        e["launches"] = max(len(v) for v in cs.values())
+        if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+            e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0
+        if "TCC_HIT_sum" in e and "TCC_MISS_sum" in e:
+            e["l2_hit_rate"] = e["TCC_HIT_sum"] / (e["TCC_HIT_sum"] + e["TCC_MISS_sum"])
+        out[k] = e
+    json.dump({"source": "rocprofv3 --kernel-trace --pmc <group> -- python3 tools/pmc_run.py (N=256, 64 eager "
+                         "iterations), one group per pass: {TCC_HIT_sum,TCC_MISS_sum}, FETCH_SIZE, WRITE_SIZE; "
+                         "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts wide reads at half)",
+               "kernels": out}, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
