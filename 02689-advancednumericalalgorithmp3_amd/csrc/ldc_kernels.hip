@@ -44,6 +44,13 @@ __device__ __forceinline__ v4d ldfrag(const double* X, int ld, int r0, int k0, i
   return *reinterpret_cast<const v4d*>(X + (size_t)(r0 + (lane & 15)) * ld + k0 + 4 * (lane >> 4));
 }
 
+// wave-uniform value that no thread of THIS launch writes: scalar load (waits on lgkmcnt, not on the
+// vector-memory queue behind which the operand prefetch sits)
+template <typename T>
+__device__ __forceinline__ T sload(const T* p) {
+  return *(const __attribute__((address_space(4))) T*)p;
+}
+
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
@@ -130,6 +137,7 @@ struct StageArgs {
   const double *Dx, *D2x, *Dy, *D2y, *IxF, *GxF;
   const double *Uin, *UinT, *Vin, *VinT;  // stage input state
   const double *U0, *V0, *P0;             // step-start state (aliases the outputs when LAST)
+  const double *U0T, *V0T;                // its transposed copies (read by the column nodes of index M-1)
   const double *T1T, *T2T;                // pressure transforms (GP only)
   double *PX, *PY;                        // grad p: written when GP, read otherwise
   double *Uout, *UoutT, *Vout, *VoutT, *Pout;
@@ -141,7 +149,8 @@ struct StageArgs {
   const double* scal;
   int* ctrl;
   double* partials;
-  int ablate;                             // timing experiments only: 1 skip MFMAs, 2 skip operand loads
+  int ablate;                             // timing experiments only: 1 skip MFMAs, 2 skip operand loads,
+                                          // 4 no stage-4 reduction, 8 no transposed stores, 16 no M-1 nodes, 32 no p store, 64 cycle stamps
   double* dump[11];
 };
 
@@ -152,6 +161,11 @@ static_assert(PS_NSUM == 8, "stage-4 reduction assigns one wave per sum");
 
 constexpr int kStageWaves = 8;                 // 2 waves per SIMD: needed to saturate the f64 MFMA pipe
 constexpr int kStageThreads = 64 * kStageWaves;
+// timing experiments (ldc_debug_stamps): cycle stamps per wave at fixed points of the stage kernel
+#define LDC_STAMP(k) do { if ((a.ablate & 64) && lane == 0) \
+  a.dump[0][((size_t)blockIdx.x * kStageWaves + wv) * 8 + (k)] = (double)__builtin_amdgcn_s_memtime(); } while (0)
+constexpr int kEdgeRowDoubles = 6 * 4 * 16;    // per wave: 6 rows of index M-1 x 4 groups x 16 (tail needs T <= 16)
+constexpr size_t kLdsLimit = 160 * 1024;
 
 __device__ __forceinline__ double dot4(const v4d& x, const v4d& y) {
   return (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]);
@@ -182,24 +196,28 @@ struct ExtraFrags {    // operands of the fifth contraction: single-buffered (lo
   v4d a2, b2;          // consumed by that group's LAST four MFMAs, ~1600 cycles later)
 };
 
+// (timing switch `ablate & 2`: every lane reads element 0 instead -- same instructions, no operand traffic;
+//  a branch around the loads would make the compiler wait for them at the join)
 __device__ __forceinline__ void load_role(RoleFrags& f, const RoleOps& o, int LD, int r0, int c0, int k0, int lane) {
-  if (o.ablate & 2) {
-    const double x = 1e-3 * lane + k0;
-    f.a0 = (v4d){x, x, x, x}; f.a1 = f.a0; f.b0 = f.a0; f.b1 = f.a0;
-    return;
-  }
+  const int keep = (o.ablate & 2) ? 0 : 1;
+  r0 *= keep; c0 *= keep; k0 *= keep; lane *= keep;
   f.a0 = ldfrag(o.A0, LD, r0, k0, lane); f.a1 = ldfrag(o.A1, LD, r0, k0, lane);
   f.b0 = ldfrag(o.B0, LD, c0, k0, lane); f.b1 = ldfrag(o.B1, LD, c0, k0, lane);
 }
 
 __device__ __forceinline__ void load_extra(ExtraFrags& x, const RoleOps& o, int LD, int r0, int c0, int k0, int lane) {
-  if (o.ablate & 2) {
-    const double y = 2e-3 * lane + k0;
-    x.a2 = (v4d){y, y, y, y}; x.b2 = x.a2;
-    return;
-  }
+  const int keep = (o.ablate & 2) ? 0 : 1;
+  r0 *= keep; c0 *= keep; k0 *= keep; lane *= keep;
   if (o.x4 != 1) x.a2 = ldfrag(o.A2, LD, r0, k0, lane);
   if (o.x4 != 2) x.b2 = ldfrag(o.B2, LD, c0, k0, lane);
+}
+
+// LDS-direct 16-byte load: lane l's 16 bytes land at lds_dst + 16*l bytes (lds_dst wave-uniform);
+// no registers, counted by vmcnt like any load (semantics pinned by tools/probes/dma_probe.hip)
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void dma16(const double* src, double* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
 template <bool GP, int NA>
@@ -228,8 +246,8 @@ __device__ __forceinline__ void mfma_role(const RoleFrags& f, const ExtraFrags& 
 
 // Index M-1 lies outside the MFMA tiles when 16*T == M-1 (`tail`).  The residual at those
 // nodes feeds only ||R_u||, ||R_v|| (quirk Q4: boundary nodes count) but must be exact.
-// Tiles of the last tile row / column get it almost for free: the row (column) vector of
-// index M-1 dotted with fragments that are already in registers, on the otherwise idle VALU.
+// A tile that holds the right fragments gets it cheaply: the row (column) vector of index M-1
+// (staged in LDS) dotted with fragments that are already in registers, on the VALU next to the MFMAs.
 //   er[ai][bj] : row node  (M-1, c0+idx) = A_i[M-1, k] . B_j[c0+idx, k]
 //   ec[ai][bj] : col node  (r0+idx, M-1) = A_i[r0+idx, k] . B_j[M-1, k]
 //   ek[ai][bj] : corner    (M-1, M-1)
@@ -243,40 +261,43 @@ struct EdgeAcc {
 // GP : the fifth contraction (grad p, or grad omega by o.x4)
 template <int VEL, bool GP>
 __device__ __forceinline__ void edge_group(EdgeAcc& e, const RoleFrags& f, const ExtraFrags& x, const RoleOps& o, int LD,
-                                           int m1, int k0, int lane, bool rowE, bool colE) {
-  const size_t off = (size_t)m1 * LD + k0 + 4 * (lane >> 4);
-  auto row_of = [&](const double* X) { return *reinterpret_cast<const v4d*>(X + off); };
+                                           const double* erow, int n, int lane, bool rowE, bool colE, bool cornE) {
+  // erow: this WAVE's pieces of the six rows of index M-1 (slots A0 A1 A2 B0 B1 B2) x its (at most four)
+  // groups x 16 doubles, put into LDS by LDS-direct loads at kernel entry: no registers, no barrier, and
+  // the reads here keep the vector-memory queue (the fragment prefetch) out of the way.
+  const int off = n * 16 + 4 * (lane >> 4);
+  auto row_of = [&](int slot) { return *reinterpret_cast<const v4d*>(erow + slot * 64 + off); };
   v4d ar0, ar1, xr, bc0, bc1, yc;
   const bool need_a0_row = (VEL != 0) || (GP && o.x4 == 1);
   const bool need_b0_col = (VEL == 1) || (VEL == 2 && o.role == 1) || (GP && o.x4 == 2);
   const bool need_b1_col = (VEL == 1) || (VEL == 2 && o.role == 0);
+  if (rowE || cornE) {
+    if (need_a0_row) ar0 = row_of(0);
+    if (VEL == 1) ar1 = row_of(1);
+    if (GP) xr = (o.x4 == 1) ? ar0 : row_of(2);
+  }
+  if (colE || cornE) {
+    if (need_b0_col) bc0 = row_of(3);
+    if (need_b1_col) bc1 = row_of(4);
+    if (GP) yc = (o.x4 == 2) ? bc0 : row_of(5);
+  }
   if (rowE) {
-    if (need_a0_row) ar0 = row_of(o.A0);
     if (VEL == 1) {
-      ar1 = row_of(o.A1);
       e.er[0] += dot4(ar0, f.b0); e.er[1] += dot4(ar0, f.b1);
       e.er[2] += dot4(ar1, f.b0); e.er[3] += dot4(ar1, f.b1);
     }
     if (VEL == 2) e.er[0] += dot4(ar0, o.role == 0 ? f.b1 : f.b0);
-    if (GP) {
-      xr = (o.x4 == 1) ? ar0 : row_of(o.A2);
-      e.er[4] += dot4(xr, (o.x4 == 2) ? f.b0 : x.b2);
-    }
+    if (GP) e.er[4] += dot4(xr, (o.x4 == 2) ? f.b0 : x.b2);
   }
   if (colE) {
-    if (need_b0_col) bc0 = row_of(o.B0);
-    if (need_b1_col) bc1 = row_of(o.B1);
     if (VEL == 1) {
       e.ec[0] += dot4(f.a0, bc0); e.ec[1] += dot4(f.a0, bc1);
       e.ec[2] += dot4(f.a1, bc0); e.ec[3] += dot4(f.a1, bc1);
     }
     if (VEL == 2) e.ec[0] += dot4(f.a0, o.role == 0 ? bc1 : bc0);
-    if (GP) {
-      yc = (o.x4 == 2) ? bc0 : row_of(o.B2);
-      e.ec[4] += dot4((o.x4 == 1) ? f.a0 : x.a2, yc);
-    }
+    if (GP) e.ec[4] += dot4((o.x4 == 1) ? f.a0 : x.a2, yc);
   }
-  if (rowE && colE) {
+  if (cornE) {
     if (VEL == 1) {
       e.ek[0] += dot4(ar0, bc0); e.ek[1] += dot4(ar0, bc1);
       e.ek[2] += dot4(ar1, bc0); e.ek[3] += dot4(ar1, bc1);
@@ -315,14 +336,15 @@ __device__ __forceinline__ void stage_block_reduce(double (&sums)[NV], double (&
 
 // dynamic LDS carve (doubles): [0, RED) per-wave accumulators; then edge partials, two
 // transposition tiles and the block-reduction scratch
-template <bool GP>
+template <bool GP, bool EDGES>
 struct StageLds {
   static constexpr int NA = GP ? 5 : 4;
   static constexpr int RED = kStageWaves * NA * 4 * 64;
   static constexpr int EDGE = RED;                         // [wave][15][16]
   static constexpr int TILE = EDGE + kStageWaves * 15 * 16;  // 3 x 16 x 17
   static constexpr int SCR = TILE + 3 * 16 * 17;           // kStageWaves * PS_N
-  static constexpr int TOTAL = SCR + kStageWaves * PS_N;
+  static constexpr int EROW = SCR + kStageWaves * PS_N;    // [wave][6 rows of index M-1][4 groups][16]
+  static constexpr int TOTAL = EROW + (EDGES ? kStageWaves * kEdgeRowDoubles : 0);
   static constexpr size_t BYTES = sizeof(double) * TOTAL;
 };
 
@@ -340,7 +362,9 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   const StageArgs& a = BATCH ? a_arr[blockIdx.y] : a_val;
   constexpr bool GP = GPV || (DIAG == 2);      // "has a fifth contraction" (grad p or grad omega)
   static_assert(!(GPV && DIAG == 2), "stage 2 of SG carries no pressure contraction");
-  using L = StageLds<GP>;
+  constexpr int VEL = (LAST || DUMP) ? 1 : (DIAG == 1 ? 2 : 0);   // what the nodes of index M-1 need here
+  constexpr bool EDGES = GP || (VEL != 0);
+  using L = StageLds<GP, EDGES>;
   constexpr int NA = L::NA;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* red = lds;
@@ -352,10 +376,16 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   int I, J;
   tile_of_block((int)blockIdx.x, T, I, J);
   const int r0 = 16 * I, c0 = 16 * J;
-  constexpr int VEL = (LAST || DUMP) ? 1 : (DIAG == 1 ? 2 : 0);   // what the nodes of index M-1 need here
-  constexpr bool EDGES = GP || (VEL != 0);
-  const bool rowE = EDGES && a.tail && (I == T - 1);
-  const bool colE = EDGES && a.tail && (J == T - 1);
+  // The nodes of index M-1 are spread over 2T+1 tiles, one job each (the VALU dot products of a job cost a
+  // tile ~0.7 us; all three jobs in the corner tile made it the slowest of the launch by 2-3 us):
+  //   row nodes (M-1, 16J + idx) need the B fragments of column block J  -> the diagonal tile (J, J)
+  //   column nodes (16I + idx, M-1) need the A fragments of row block I  -> tile (I, I+1 mod T)
+  //   the corner node needs no fragments                                 -> tile (0, 2) (T < 3: tile (0, 0))
+  const bool etile = EDGES && a.tail && !(a.ablate & 16);
+  const bool rowE = etile && (I == J);
+  const bool colE = etile && (J == (I + 1) % T);
+  const bool cornE = etile && (T >= 3 ? (I == 0 && J == 2) : (I == 0 && J == 0));
+  const bool anyE = rowE || colE || cornE;     // block-uniform
 
   RoleOps o;
   o.ablate = a.ablate;
@@ -364,16 +394,36 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   if (role == 0) { o.A0 = a.Dx; o.A1 = a.D2x; o.B0 = a.UinT; o.B1 = a.VinT; o.A2 = a.GxF; o.B2 = (DIAG == 2) ? a.WT : a.T1T; }
   else           { o.A0 = a.Uin; o.A1 = a.Vin; o.B0 = a.Dy; o.B1 = a.D2y; o.A2 = (DIAG == 2) ? a.W : a.IxF; o.B2 = a.T2T; }
 
+  LDC_STAMP(0);
+  // this wave's K groups: kq, kq+4, ... (ng of them); group n starts at k = gk(n)
+  // this wave's K groups: kq, kq+4, ... (ng of them); group n starts at k = gk(n)
+  const int ng = (T - kq + 3) / 4;
+  auto gk = [&](int n) { return 16 * (kq + 4 * n); };
+  double* erow = lds + L::EROW + wv * kEdgeRowDoubles;
+
+  // ---- tiles with an index-(M-1) job: this wave's pieces of the six rows, LDS-direct, issued first
+  if (anyE) {
+    const int h = lane & 1, q = (lane >> 1) & 3, gi = (lane >> 3) & 3, sl = lane >> 5;
+    const size_t off = (size_t)m1 * LD + 16 * (kq + 4 * gi) + 4 * q + 2 * h;
+    const bool live = (kq + 4 * gi) < T;
+    const bool needA = rowE || cornE, needB = colE || cornE;
+    const double* s01 = sl ? o.A1 : o.A0;
+    const double* s23 = sl ? o.B0 : o.A2;
+    const double* s45 = sl ? o.B2 : o.B1;
+    if (live && needA && s01 != nullptr) dma16(s01 + off, erow);
+    if (live && (sl ? needB : needA) && s23 != nullptr) dma16(s23 + off, erow + 128);
+    if (live && needB && s45 != nullptr) dma16(s45 + off, erow + 256);
+  }
+
   // ---- first fragments in flight before anything else ------------------------------------
-  int g = kq;
   RoleFrags fa, fb;
   ExtraFrags fx;
-  load_role(fa, o, LD, r0, c0, 16 * (g < T ? g : 0), lane);
+  load_role(fa, o, LD, r0, c0, ng > 0 ? gk(0) : 0, lane);
 
   // the latch and dt are read only now, behind the first operand loads (reads are harmless)
-  if (!DUMP && a.ctrl[LDC_CTRL_DONE] != 0) return;
-  const int step0 = a.ctrl[LDC_CTRL_STEP];
-  const double adt = a.alpha * a.scal[LDC_SCAL_DT];
+  if (!DUMP && sload(a.ctrl + LDC_CTRL_DONE) != 0) return;
+  const int step0 = sload(a.ctrl + LDC_CTRL_STEP);
+  const double adt = a.alpha * sload(a.scal + LDC_SCAL_DT);
 
   // ---- pointwise operands of the epilogue, issued now so that they land under the MFMAs ----------
   // threads 0..255 own node (i, j) of the tile; in tiles of the last tile row / column threads 256..
@@ -381,27 +431,40 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   const int ti = 4 * (wv & 3) + (lane >> 4), tj = lane & 15;
   const bool owner = tid < 256;
   const int ekind = (tid - 256) >> 4, eidx = (tid - 256) & 15;
-  const bool edge_thr = !owner && ((ekind == 0 && rowE) || (ekind == 1 && colE) || (ekind == 2 && eidx == 0 && rowE && colE));
+  const bool edge_thr = !owner && ((ekind == 0 && rowE) || (ekind == 1 && colE) || (ekind == 2 && eidx == 0 && cornE));
   const int i = owner ? (r0 + ti) : ((ekind == 1) ? (r0 + eidx) : m1);
   const int j = owner ? (c0 + tj) : ((ekind == 0) ? (c0 + eidx) : m1);
   const size_t ij = (size_t)i * LD + j;
   double uin = 0, vin = 0, u0 = 0, v0 = 0, p0 = 0, px = 0, py = 0;
   double dxl = 0, d2xl = 0, dyl = 0, d2yl = 0, ue = 0, ve = 0, un_ = 0, vn_ = 0, lidv = 0, wq = 0, we = 0, wn = 0;
+  // column nodes (r0+idx, M-1) read the transposed copies: contiguous instead of one cache line per lane
+  // (16 lanes x 10 operands x a cold line each held the whole wave back by ~2 us); their grad p sits in
+  // the padding row M of PX / PY, put there by stage 1
+  const bool colnode = !owner && ekind == 1;
+  const size_t ijT = (size_t)j * LD + i;
   if (owner || edge_thr) {
-    uin = a.Uin[ij]; vin = a.Vin[ij];
-    if (!DUMP) { u0 = a.U0[ij]; v0 = a.V0[ij]; }
+    uin = (colnode ? a.UinT : a.Uin)[colnode ? ijT : ij];
+    vin = (colnode ? a.VinT : a.Vin)[colnode ? ijT : ij];
+    if (!DUMP) {
+      u0 = (colnode ? a.U0T : a.U0)[colnode ? ijT : ij];
+      v0 = (colnode ? a.V0T : a.V0)[colnode ? ijT : ij];
+    }
     if (owner && !DUMP && a.Pout != nullptr) p0 = a.P0[ij];
-    if (!GPV && (owner || VEL == 1)) { px = a.PX[ij]; py = a.PY[ij]; }
+    if (!GPV && (owner || VEL == 1)) {
+      const size_t ip = colnode ? (size_t)M * LD + i : ij;
+      px = a.PX[ip]; py = a.PY[ip];
+    }
     if (a.tail) {
       dxl = a.DxL[i]; d2xl = a.D2xL[i]; dyl = a.DyL[j]; d2yl = a.D2yL[j];
       ue = a.Uin[(size_t)m1 * LD + j]; ve = a.Vin[(size_t)m1 * LD + j];    // east-wall row
-      un_ = a.Uin[(size_t)i * LD + m1]; vn_ = a.Vin[(size_t)i * LD + m1];  // lid column
-      if (DIAG == 2) { we = a.W[(size_t)m1 * LD + j]; wn = a.W[(size_t)i * LD + m1]; }
+      un_ = a.UinT[(size_t)m1 * LD + i]; vn_ = a.VinT[(size_t)m1 * LD + i];  // lid column, read along the transposed copy
+      if (DIAG == 2) { we = a.W[(size_t)m1 * LD + j]; wn = a.WT[(size_t)m1 * LD + i]; }
     }
     lidv = a.ulid[i];
     if (LAST || DIAG != 0) wq = a.wx[i] * a.wy[j];
   }
 
+  LDC_STAMP(1);
   // ---- contraction over k: this wave's quarter, loads one group ahead (A/B ping-pong) --------
   v4d acc[NA];
 #pragma unroll
@@ -409,26 +472,29 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   EdgeAcc ea;
 #pragma unroll
   for (int q = 0; q < 5; ++q) { ea.er[q] = 0.0; ea.ec[q] = 0.0; ea.ek[q] = 0.0; }
-  for (; g < T; g += 2 * 4) {
-    const int g1 = g + 4, g2 = g + 8;
-    if (GP) load_extra(fx, o, LD, r0, c0, 16 * g, lane);          // first: loads return in issue order
-    load_role(fb, o, LD, r0, c0, 16 * (g1 < T ? g1 : g), lane);   // clamped: harmless reload
+  // Loads one group ahead (A/B ping-pong).  Deeper prefetch (a third group parked in LDS by LDS-direct
+  // loads) and per-tile rotation of the k order were measured and bought nothing: the loop is bound by
+  // the ~37 GB/s per CU at which the cold L2 delivers the 278 KB of operands, not by latency.
+  for (int n = 0; n < ng; n += 2) {
+    if (GP) load_extra(fx, o, LD, r0, c0, gk(n), lane);          // first: loads return in issue order
+    load_role(fb, o, LD, r0, c0, gk(n + 1 < ng ? n + 1 : n), lane);   // clamped: harmless reload
     mfma_role<GP, NA>(fa, fx, acc, a.ablate, o.x4);
-    if (rowE || colE) edge_group<VEL, GP>(ea, fa, fx, o, LD, m1, 16 * g, lane, rowE, colE);
-    if (g1 < T) {
-      if (GP) load_extra(fx, o, LD, r0, c0, 16 * g1, lane);
-      load_role(fa, o, LD, r0, c0, 16 * (g2 < T ? g2 : g1), lane);
+    if (anyE) edge_group<VEL, GP>(ea, fa, fx, o, LD, erow, n, lane, rowE, colE, cornE);
+    if (n + 1 < ng) {
+      if (GP) load_extra(fx, o, LD, r0, c0, gk(n + 1), lane);
+      load_role(fa, o, LD, r0, c0, gk(n + 2 < ng ? n + 2 : n + 1), lane);
       mfma_role<GP, NA>(fb, fx, acc, a.ablate, o.x4);
-      if (rowE || colE) edge_group<VEL, GP>(ea, fb, fx, o, LD, m1, 16 * g1, lane, rowE, colE);
+      if (anyE) edge_group<VEL, GP>(ea, fb, fx, o, LD, erow, n + 1, lane, rowE, colE, cornE);
     }
   }
 
+  LDC_STAMP(2);
   // ---- all partial results to LDS ---------------------------------------------------------------
 #pragma unroll
   for (int q = 0; q < NA; ++q)
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[((wv * NA + q) * 4 + r) * 64 + lane] = acc[q][r];
-  if (rowE || colE) {
+  if (anyE) {
     double* er = lds + L::EDGE + wv * 15 * 16;
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
@@ -439,6 +505,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   }
   __syncthreads();
 
+  LDC_STAMP(3);
   // sum of one accumulator over the four K-quarters of a role, at this thread's node
   auto rsum = [&](int rl, int q) {
     const int w = wv & 3;
@@ -491,7 +558,10 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
     if (GPV) {
       px = valid ? C(0, 4) : 0.0;   // row M-1 of T1T/T2T meets a zero column of GxF/IxF: no completion term
       py = valid ? C(1, 4) : 0.0;
-      if (!DUMP) { a.PX[ij] = px; a.PY[ij] = py; }
+      if (!DUMP) {
+        a.PX[ij] = px; a.PY[ij] = py;
+        if (colnode) { a.PX[(size_t)M * LD + i] = px; a.PY[(size_t)M * LD + i] = py; }
+      }
     }
     if (DIAG == 1) {
       const double w = valid ? (vx - uy) : 0.0;          // sg.py:510-522 on phi^(n+1) (= this stage's input)
@@ -522,7 +592,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
       else if (i == 0 || i == M - 1 || j == 0) { un = 0.0; vn = 0.0; }
       a.Uout[ij] = un;
       a.Vout[ij] = vn;
-      if (a.Pout != nullptr) a.Pout[ij] = interior ? (p0 + adt * Rp) : 0.0;
+      if (a.Pout != nullptr && !(a.ablate & 32)) a.Pout[ij] = interior ? (p0 + adt * Rp) : 0.0;
       tu[ti * 17 + tj] = un;
       tv[ti * 17 + tj] = vn;
       if (LAST) {
@@ -548,8 +618,10 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   }
   if (DUMP) return;
 
+  LDC_STAMP(4);
   __syncthreads();
-  if (owner) {
+  LDC_STAMP(5);
+  if (owner && !(a.ablate & 8)) {
     const int tr = tid >> 4, tc = tid & 15;   // write UT[c0+tr][r0+tc] = tile[tc][tr]
     const size_t ot = (size_t)(c0 + tr) * LD + r0 + tc;
     a.UoutT[ot] = tu[tc * 17 + tr];
@@ -573,7 +645,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
       a.ctrl[LDC_CTRL_DROWS] = (int)gridDim.x;
     }
   }
-  if (LAST) {
+  if (LAST && !(a.ablate & 4)) {
     // block reduction through LDS (the accumulator region is free again): one wave per value,
     // fixed order; ten shuffle trees per wave would cost far more than this transpose
 #pragma unroll
@@ -598,6 +670,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
     }
     if (blockIdx.x == 0 && tid == 0) a.ctrl[LDC_CTRL_STEP] = step0 + 1;   // one more state update done
   }
+  LDC_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1122,6 +1195,7 @@ struct ldc_solver {
   int n_pedge_blocks;
   int iters_per_graph;
   int ablate;
+  double* stamps;            // ldc_debug_stamps
   hipGraphExec_t graph[2];   // [with_diagnostics]
   hipStream_t capture_stream;
 };
@@ -1163,6 +1237,7 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
   a.alpha = alphas[k];
   a.Dx = p.Dx; a.D2x = p.D2x; a.Dy = p.Dy; a.D2y = p.D2y; a.IxF = p.IxF; a.GxF = p.GxF;
   a.U0 = p.U; a.V0 = p.V; a.P0 = p.P;
+  a.U0T = p.UT; a.V0T = p.VT;
   a.T1T = p.T1T; a.T2T = p.T2T; a.PX = p.PX; a.PY = p.PY;
   a.ulid = p.ulid; a.wx = p.wx; a.wy = p.wy; a.scal = p.scal; a.ctrl = p.ctrl;
   a.DxL = p.DxL; a.D2xL = p.D2xL; a.DyL = p.DyL; a.D2yL = p.D2yL;
@@ -1170,7 +1245,8 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
   a.W = p.W; a.WT = p.WT;
   a.partZ0 = p.partials + p.partials_stride; a.partP0 = p.partials + 3 * p.partials_stride;
   a.stride = p.partials_stride;
-  a.ablate = s->ablate;
+  a.ablate = s->stamps ? s->ablate : (s->ablate & ~64);
+  a.dump[0] = s->stamps;
   // ping-pong: 0: S0 -> A, 1: A -> B, 2: B -> A, 3: A -> S0 (in place)
   const double *in[4][4] = {{p.U, p.UT, p.V, p.VT}, {p.UA, p.UAT, p.VA, p.VAT},
                             {p.UB, p.UBT, p.VB, p.VBT}, {p.UA, p.UAT, p.VA, p.VAT}};
@@ -1191,10 +1267,11 @@ template <bool GP, bool LAST, bool DUMP, bool BATCH, int DIAG>
 int launch_stage_kernel(const StageArgs& a, const StageArgs* arr, int nt, int nbatch, hipStream_t st) {
   static bool attr_set = false;   // dynamic LDS above 64 KiB must be enabled once per kernel
   auto kern = stage_kernel<GP, LAST, DUMP, BATCH, DIAG>;
-  constexpr size_t lds_bytes = StageLds<GP || DIAG == 2>::BYTES;
+  constexpr size_t lds_bytes = StageLds<GP || DIAG == 2, GP || DIAG != 0 || LAST || DUMP>::BYTES;
+  static_assert(lds_bytes <= kLdsLimit, "stage kernel LDS");
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes));
+                                (int)kLdsLimit));
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(nt, nbatch), dim3(kStageThreads), lds_bytes, st, a, arr);
@@ -1419,10 +1496,14 @@ int ldc_device_check(char* arch, int arch_len) {
 
 int ldc_solver_create(const ldc_problem* d, ldc_solver** out) {
   if (!d || !out) return LDC_E_ARG;
-  if (d->M < 4 || d->T < 1 || d->T != (d->M - 1 + 15) / 16) return LDC_E_ARG;
+  if (d->M < 4 || d->T < 1) return LDC_E_ARG;
   if (d->LD % 16 != 0 || d->LD < 16 * d->T + 16 || d->LD < d->M) return LDC_E_ARG;
-  if (d->tail != ((16 * d->T == d->M - 1) ? 1 : 0)) return LDC_E_ARG;
+  // either T = ceil((M-1)/16) with tail = (16 T == M-1), or every index inside the tiles (T = ceil(M/16), tail = 0)
+  const bool lay_a = d->T == (d->M - 1 + 15) / 16 && d->tail == ((16 * d->T == d->M - 1) ? 1 : 0);
+  const bool lay_b = d->T == (d->M + 15) / 16 && d->tail == 0;
+  if (!lay_a && !lay_b) return LDC_E_ARG;
   if (d->rec_cap < 1 || (d->stage_pressure != 0 && d->stage_pressure != 1)) return LDC_E_ARG;
+  if (d->tail && d->T > 16) return LDC_E_ARG;   // the index-(M-1) jobs stage four groups per wave
   if (d->stage_pressure && (!d->PA || !d->PB)) return LDC_E_ARG;
   const void* req[] = {d->Dx, d->D2x, d->Dy, d->D2y, d->IxF, d->GxF, d->IyF, d->GyF, d->wx, d->wy, d->ulid,
                        d->DxL, d->D2xL, d->DyL, d->D2yL,
@@ -1438,6 +1519,7 @@ int ldc_solver_create(const ldc_problem* d, ldc_solver** out) {
   if (d->partials_stride < (int64_t)(s->nt + s->n_edge_blocks) * LDC_NPART) { delete s; return LDC_E_ARG; }
   s->iters_per_graph = 32;
   s->ablate = 0;
+  s->stamps = nullptr;
   s->graph[0] = s->graph[1] = nullptr;
   s->capture_stream = nullptr;
   *out = s;
@@ -1462,6 +1544,12 @@ int ldc_solver_set_graph_iters(ldc_solver* s, int n) {
 int ldc_debug_ablate(ldc_solver* s, int mask) {
   if (!s) return LDC_E_STATE;
   s->ablate = mask;
+  return 0;
+}
+
+int ldc_debug_stamps(ldc_solver* s, double* buf) {
+  if (!s) return LDC_E_STATE;
+  s->stamps = buf;
   return 0;
 }
 

@@ -84,6 +84,7 @@ def lib() -> C.CDLL:
     L.ldc_poisson_fastdiag.argtypes = [_dp] * 10 + [C.c_int, C.c_int, _dp]
     L.ldc_vortex_extrema.argtypes = [_dp, _dp, _dp, _dp, C.c_int, C.c_int, _dp, _dp, _dp]
     L.ldc_debug_ablate.argtypes = [_dp, C.c_int]
+    L.ldc_debug_stamps.argtypes = [_dp, C.c_void_p]
     L.ldc_mfma_selftest.argtypes = [_dp, _dp, _dp, _dp]
     L.ldc_mfma_peak.argtypes = [_dp, C.c_int, C.c_int, _dp]
     for name in EXPORTS:
@@ -99,7 +100,7 @@ EXPORTS = (
     "ldc_stage", "ldc_pressure_transform", "ldc_diagnostics", "ldc_finalize", "ldc_prime", "ldc_global_quantities",
     "ldc_solver_enqueue", "ldc_solver_set_graph_iters", "ldc_residual_debug", "ldc_gemm_nt",
     "ldc_batch_workspace_bytes", "ldc_batch_create", "ldc_batch_destroy", "ldc_batch_enqueue",
-    "ldc_poisson_fastdiag", "ldc_vortex_extrema", "ldc_mfma_selftest", "ldc_mfma_peak", "ldc_debug_ablate",
+    "ldc_poisson_fastdiag", "ldc_vortex_extrema", "ldc_mfma_selftest", "ldc_mfma_peak", "ldc_debug_ablate", "ldc_debug_stamps",
 )
 
 

@@ -116,8 +116,12 @@ class SGSolver(LidDrivenCavitySolver):
             x, np.full_like(x, p.Ly), lid_velocity=p.lid_velocity, Lx=p.Lx, Ly=p.Ly)
         self.u_lid = u_lid
         # geometry of the MFMA tiling
+        # (N a multiple of 16 up to 256: index M-1 stays outside the tiles so that T*T work-groups fill
+        #  the chip exactly; beyond that the grid is large anyway and index M-1 gets a tile row of its own)
         self.T = (M - 1 + 15) // 16
-        self.tail = 1 if 16 * self.T == M - 1 else 0
+        self.tail = 1 if (16 * self.T == M - 1 and self.T <= 16) else 0
+        if 16 * self.T == M - 1 and not self.tail:
+            self.T += 1
         self.LD = 16 * self.T + 16
 
     def _alloc_device(self):

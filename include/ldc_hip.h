@@ -76,7 +76,8 @@ typedef struct ldc_problem {
   int32_t M;      /* nodes per axis, N+1                                               */
   int32_t LD;     /* leading dimension of every padded array                           */
   int32_t T;      /* 16x16 tiles per axis done on MFMA: ceil((M-1)/16)                 */
-  int32_t tail;   /* 1 when 16*T == M-1: index M-1 is handled by rank-1/edge paths     */
+  int32_t tail;   /* 1 when 16*T == M-1: index M-1 is handled by rank-1/edge paths (needs
+                     T <= 16); T = ceil(M/16), tail = 0 is always valid                 */
   /* physics / control (reference conf/solver/spectral/sg.yaml, conf/config.yaml)      */
   double nu;          /* 1/Re                                                          */
   double beta2;       /* beta_squared                                                  */
@@ -189,6 +190,9 @@ int ldc_vortex_extrema(const double *Psi, const double *W, const double *x, cons
 /* timing experiments only (results are WRONG while set): bit 0 skips the MFMAs, bit 1 the   */
 /* operand loads of the stage kernel                                                       */
 int ldc_debug_ablate(ldc_solver *s, int mask);
+/* Timing experiments: with mask bit 64 set every wave of the stage kernel writes seven cycle stamps
+ * (s_memtime) to buf[((block * 8 + wave) * 8 + point)]; buf holds T*T*64 doubles.  NULL switches off. */
+int ldc_debug_stamps(ldc_solver *s, double *buf);
 
 /* hardware self-test: D = A(16x4) * B(4x16) with the f64 MFMA; used by tests to pin the  */
 /* operand / result lane maps                                                             */

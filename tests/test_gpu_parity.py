@@ -171,6 +171,34 @@ def test_n256_short_run_vs_oracle():
     assert rel(rec[:, 6], np.array(Ps)) < 1e-9
 
 
+@pytest.mark.parametrize("N,Re", [(8, 50.0), (12, 50.0), (48, 100.0), (96, 400.0), (100, 400.0), (272, 1000.0)])
+def test_short_run_records_vs_oracle(N, Re):
+    """Every history column against the oracle at sizes that place the index-(M-1) work differently:
+    one tile holding all three jobs (N = 16 is in the fixtures), T = 3 (corner job on tile (0, 2)), T = 6,
+    sizes that are no multiple of 16, and a multiple of 16 beyond 256 (index M-1 inside the tiles)."""
+    K = 14 if N <= 100 else 12
+    o = orc.OracleSG(N, Re)
+    rows = []
+    for _ in range(K):
+        up, vp = o.u.copy(), o.v.copy()
+        dt = o.step()
+        nrm = lambda a, b: np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-12)
+        rows.append([max(nrm(o.u, up), nrm(o.v, vp)), *o.residual_norms(),
+                     o.energy(), o.enstrophy(), o.palinstrophy(), dt])
+    want = np.array(rows)
+    s = make(N, Re)
+    assert (s.tail == 1) == (N % 16 == 0 and N <= 256)
+    rec = s.run_iterations(K)
+    M = N + 1
+    assert np.max(np.abs(s.arrays.u.reshape(M, M) - o.u)) < 1e-12
+    assert np.max(np.abs(s.arrays.v.reshape(M, M) - o.v)) < 1e-12
+    assert np.max(np.abs(s.arrays.p.reshape(M - 2, M - 2) - o.p)) < 1e-12
+    assert rel(rec[:, 7], want[:, 7]) < 1e-12
+    assert np.max(np.abs(rec[:, 0] - want[:, 0]) / (np.abs(want[:, 0]) + 1e-9)) < 1e-8
+    for c in range(1, 7):
+        assert rel(rec[:, c], want[:, c]) < (1e-10 if c < 5 else 1e-9), c
+
+
 def test_solve_converges_like_reference(golden_dir):
     """Full solve() at N=32, Re=100, tol 1e-6: the reference stops after 59 649 iterations."""
     meta = json.loads((golden_dir / "g7_converged_N32_Re100.json").read_text())["metrics"]

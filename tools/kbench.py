@@ -5,6 +5,7 @@ Development aid (not part of the product path).  Usage:
     python tools/kbench.py [--N 256] [--reps 200]
 """
 import argparse
+import os
 import sys
 from pathlib import Path
 
@@ -61,7 +62,8 @@ for name, fn, fl in rows:
     med, best = burst(fn)
     tf = fl / med / 1e6 if fl else 0.0
     print(f"{name:34s} median {med:8.2f} us  best {best:8.2f} us  {tf:6.2f} TFLOP/s")
-for mask, label in ((1, "no MFMA"), (2, "no operand loads"), (3, "neither")):
+extra = [(int(m), f"mask {m}") for m in os.environ.get("KB_MASKS", "").split(",") if m]
+for mask, label in [(1, "no MFMA"), (2, "no operand loads"), (3, "neither")] + extra:
     lib.ldc_debug_ablate(h, mask)
     for name, fn, fl in rows[:6]:
         med, best = burst(fn)
