@@ -51,15 +51,34 @@ __device__ __forceinline__ T sload(const T* p) {
   return *(const __attribute__((address_space(4))) T*)p;
 }
 
+// Wave reductions on DPP lane moves (a __shfl_xor of a double is two ds_bpermute round trips per step:
+// six steps cost ~1 us in the stage-4 epilogue).  Every lane of a row of 16 ends with the row total, the
+// four row totals meet through readlane.  Fixed order => deterministic.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x) {
+  const long long b = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double lane_value(double x, int l) {
+  const long long b = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-  return x;
+  x += dpp_move<0xB1>(x);    // quad_perm [1,0,3,2]
+  x += dpp_move<0x4E>(x);    // quad_perm [2,3,0,1]
+  x += dpp_move<0x141>(x);   // row_half_mirror
+  x += dpp_move<0x140>(x);   // row_mirror
+  return (lane_value(x, 0) + lane_value(x, 16)) + (lane_value(x, 32) + lane_value(x, 48));
 }
 __device__ __forceinline__ double wave_max(double x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o));
-  return x;
+  x = fmax(x, dpp_move<0xB1>(x));
+  x = fmax(x, dpp_move<0x4E>(x));
+  x = fmax(x, dpp_move<0x141>(x));
+  x = fmax(x, dpp_move<0x140>(x));
+  return fmax(fmax(lane_value(x, 0), lane_value(x, 16)), fmax(lane_value(x, 32), lane_value(x, 48)));
 }
 // wave-cooperative dot product of two contiguous rows (fixed order => deterministic)
 __device__ __forceinline__ double dot_rows(const double* a, const double* b, int n, int lane) {
@@ -735,24 +754,25 @@ __device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t) 
     for (int r = t; r < drows; r += kThreads) v[PS_N] += pz[(size_t)r * LDC_NPART];
     for (int r = t; r < drows; r += kThreads) v[PS_N + 1] += pp[(size_t)r * LDC_NPART];
   }
+  // wave totals on DPP moves, then one value per wave through LDS (fixed order)
+  constexpr int NW = kThreads / 64;
 #pragma unroll
-  for (int q = 0; q < PS_N + 2; ++q) sm[q * kThreads + t] = v[q];
-  __syncthreads();
-  for (int h = kThreads / 2; h > 0; h >>= 1) {
-    if (t < h) {
-#pragma unroll
-      for (int q = 0; q < PS_N + 2; ++q) {
-        const bool is_max = (q == PS_UMAX || q == PS_VMAX);
-        const double x = sm[q * kThreads + t], y = sm[q * kThreads + t + h];
-        sm[q * kThreads + t] = is_max ? fmax(x, y) : (x + y);
-      }
-    }
-    __syncthreads();
+  for (int q = 0; q < PS_N + 2; ++q) {
+    const bool is_max = (q == PS_UMAX || q == PS_VMAX);
+    v[q] = is_max ? wave_max(v[q]) : wave_sum(v[q]);
+    if ((t & 63) == 0) sm[q * NW + (t >> 6)] = v[q];
   }
+  __syncthreads();
   if (t != 0) return;
   double r[PS_N + 2];
 #pragma unroll
-  for (int q = 0; q < PS_N + 2; ++q) r[q] = sm[q * kThreads];
+  for (int q = 0; q < PS_N + 2; ++q) {
+    const bool is_max = (q == PS_UMAX || q == PS_VMAX);
+    double x = sm[q * NW];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) x = is_max ? fmax(x, sm[q * NW + w]) : (x + sm[q * NW + w]);
+    r[q] = x;
+  }
   if (flush) {
     double* rec = a.rec + (size_t)((iter - 1) % a.rec_cap) * LDC_REC_LEN;
     rec[LDC_REC_Z] = 0.5 * r[PS_N];
