@@ -1,0 +1,15 @@
+"""A/B timing of the full iteration (hipGraph path, N=256): run once per library, e.g.
+    python tools/ab_iter.py; LDC_HIP_LIB=/path/to/other/libldc_hip.so python tools/ab_iter.py
+(development aid)"""
+import sys, os
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "02689-advancednumericalalgorithmp3_amd", "src"))
+import torch
+from solvers.spectral import ldc_lib as L
+from solvers.spectral.sg import SGSolver
+s = SGSolver(name="spectral", Re=1000.0, nx=256, ny=256, basis_type="chebyshev", CFL=1.5, tolerance=0.0,
+             max_iterations=10**9, check_every=4096, graph_iters=32)
+s.run_iterations(640)
+for rep in range(5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record(); s.run_iterations(3200); e1.record(); torch.cuda.synchronize()
+    print(os.environ.get("LDC_HIP_LIB", "main")[-24:], f"{e0.elapsed_time(e1) * 1e3 / 3200:.2f} us/iter")
