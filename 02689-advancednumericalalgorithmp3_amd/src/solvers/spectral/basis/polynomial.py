@@ -1,6 +1,7 @@
 """Modal interpolation on collocation nodes -- the centreline-extraction recipe.
 
-Contract: reference src/solvers/spectral/basis/polynomial.py:15-73 (Jacobi recurrence),
+Contract: reference src/solvers/spectral/basis/polynomial.py:15-73 (Jacobi recurrence), :132-345
+(derivative, Legendre-Gauss-Lobatto nodes / weights, Vandermonde matrices: the Legendre basis of the solver),
 :398-477 (``spectral_interpolate``), used by the Ghia comparison
 (src/shared/plotting/ldc/validation.py:297-322).  Post-processing, host side.
 """
@@ -24,6 +25,32 @@ def jacobi_poly(xs, alpha: float, beta: float, N: int) -> np.ndarray:
         hi = 2 * (m + 1) * (m + ab + 1) / ((s + 2) * (s + 1))
         older, newer = newer, ((mid + xs) * newer - lo * older) / hi
     return newer
+
+
+def grad_jacobi_poly(xs, alpha: float, beta: float, n: int):
+    """d/dx P_n^{(alpha,beta)} = (alpha+beta+n+1)/2 P_{n-1}^{(alpha+1,beta+1)} (reference polynomial.py:132-157)."""
+    if n == 0:
+        return np.zeros_like(np.asarray(xs, dtype=float))
+    return 0.5 * (alpha + beta + n + 1) * jacobi_poly(xs, alpha + 1, beta + 1, n - 1)
+
+
+def legendre_gauss_lobatto_nodes(num_nodes: int) -> np.ndarray:
+    """-1, the roots of P_N', +1 (reference polynomial.py:164-195)."""
+    from numpy.polynomial.legendre import Legendre
+    inner = Legendre.basis(num_nodes - 1).deriv().roots()
+    return np.sort(np.concatenate(([-1.0], inner, [1.0])))
+
+
+def legendre_gauss_lobatto_weights(num_nodes: int) -> np.ndarray:
+    """2 / (N (N+1) P_N(x_j)^2) (reference polynomial.py:198-243)."""
+    N = num_nodes - 1
+    if N == 0:
+        return np.array([2.0])
+    return 2.0 / (N * (N + 1) * jacobi_poly(legendre_gauss_lobatto_nodes(num_nodes), 0.0, 0.0, N) ** 2)
+
+
+def vandermonde_x(xs, alpha: float, beta: float) -> np.ndarray:
+    return np.stack([grad_jacobi_poly(xs, alpha, beta, n) for n in range(len(xs))], axis=1)
 
 
 def vandermonde(xs, alpha: float, beta: float, ncols: int | None = None) -> np.ndarray:

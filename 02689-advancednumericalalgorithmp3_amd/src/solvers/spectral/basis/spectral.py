@@ -82,6 +82,37 @@ class ChebyshevLobattoBasis:
         return clenshaw_curtis_weights(num_points) * (b - a) / 2
 
 
+def legendre_diff_matrix(nodes: np.ndarray) -> np.ndarray:
+    """D = Vx V^-1 on arbitrary nodes, Legendre modes (reference basis/spectral.py:93-130)."""
+    from .polynomial import vandermonde, vandermonde_x
+    return vandermonde_x(nodes, 0.0, 0.0) @ np.linalg.solve(vandermonde(nodes, 0.0, 0.0), np.eye(nodes.size))
+
+
+class LegendreLobattoBasis:
+    """LGL nodes / derivative / weights affinely mapped to ``domain`` (reference basis/spectral.py:326-407)."""
+
+    def __init__(self, domain=(-1.0, 1.0)):
+        self.domain = (float(domain[0]), float(domain[1]))
+
+    def nodes(self, num_points: int) -> np.ndarray:
+        from .polynomial import legendre_gauss_lobatto_nodes
+        xi = legendre_gauss_lobatto_nodes(num_points)
+        if self.domain == (-1.0, 1.0):
+            return xi
+        a, b = self.domain
+        return 0.5 * (b - a) * (xi + 1.0) + a
+
+    def diff_matrix(self, nodes: np.ndarray) -> np.ndarray:
+        from .polynomial import legendre_gauss_lobatto_nodes
+        a, b = self.domain
+        return (2.0 / (b - a)) * legendre_diff_matrix(legendre_gauss_lobatto_nodes(nodes.size))
+
+    def quadrature_weights(self, num_points: int) -> np.ndarray:
+        from .polynomial import legendre_gauss_lobatto_weights
+        a, b = self.domain
+        return legendre_gauss_lobatto_weights(num_points) * (b - a) / 2
+
+
 def inner_to_full_interpolation(nodes_inner: np.ndarray, nodes_full: np.ndarray) -> np.ndarray:
     """(M, M-2) matrix evaluating, on all nodes, the polynomial of degree M-3 that
     interpolates values given on the interior nodes (P_N-P_{N-2} pressure; reference

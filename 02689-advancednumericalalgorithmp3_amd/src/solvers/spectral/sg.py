@@ -18,7 +18,7 @@ import numpy as np
 from ..base import LidDrivenCavitySolver
 from ..datastructures import SpectralParameters
 from . import ldc_lib as L
-from .basis.spectral import ChebyshevLobattoBasis, inner_to_full_interpolation
+from .basis.spectral import ChebyshevLobattoBasis, LegendreLobattoBasis, inner_to_full_interpolation
 from .operators.corner import create_corner_treatment
 
 log = logging.getLogger(__name__)
@@ -66,10 +66,9 @@ class SGSolver(LidDrivenCavitySolver):
         if kind == "chebyshev":
             self.basis_x = ChebyshevLobattoBasis(domain=(0.0, p.Lx))
             self.basis_y = ChebyshevLobattoBasis(domain=(0.0, p.Ly))
-        elif kind == "legendre":
-            raise NotImplementedError(
-                "basis_type='legendre' is outside the MI355X hot path; use 'chebyshev' "
-                "(conf/solver/spectral/sg.yaml)")
+        elif kind == "legendre":          # same device path: only the host-built operators differ
+            self.basis_x = LegendreLobattoBasis(domain=(0.0, p.Lx))
+            self.basis_y = LegendreLobattoBasis(domain=(0.0, p.Ly))
         else:
             raise ValueError(f"Unknown basis_type: {p.basis_type}. Use 'legendre' or 'chebyshev'")
         if p.nx != p.ny:

@@ -84,11 +84,41 @@ def interp_inner_to_full(x_inner: np.ndarray, x_full: np.ndarray) -> np.ndarray:
     return V_fu @ np.linalg.solve(V_in, np.eye(n))
 
 
+# --------------------------------------------------------------------------- Legendre (basis_type="legendre")
+def lgl_nodes(M: int) -> np.ndarray:
+    """Legendre-Gauss-Lobatto nodes: +-1 and the roots of P_N' (basis/polynomial.py:164-195)."""
+    from numpy.polynomial.legendre import Legendre
+    roots = Legendre.basis(M - 1).deriv().roots()
+    return np.sort(np.concatenate(([-1.0], roots, [1.0])))
+
+
+def lgl_weights(M: int) -> np.ndarray:
+    """w_j = 2 / (N (N+1) P_N(x_j)^2) (basis/polynomial.py:198-243)."""
+    N = M - 1
+    if N == 0:
+        return np.array([2.0])
+    PN = jacobi_p(lgl_nodes(M), 0.0, 0.0, N)
+    return 2.0 / (N * (N + 1) * PN**2)
+
+
+def legendre_diff_reference_interval(xi: np.ndarray) -> np.ndarray:
+    """D = Vx V^-1 with V_jn = P_n(x_j), Vx_jn = P_n'(x_j) = (n+1)/2 P^{(1,1)}_{n-1}(x_j)
+    (basis/spectral.py:93-130, basis/polynomial.py:132-157, 250-345)."""
+    n = xi.size
+    V = np.zeros((n, n))
+    Vx = np.zeros((n, n))
+    for k in range(n):
+        V[:, k] = jacobi_p(xi, 0.0, 0.0, k)
+        Vx[:, k] = 0.0 if k == 0 else 0.5 * (k + 1) * jacobi_p(xi, 1.0, 1.0, k - 1)
+    return Vx @ np.linalg.solve(V, np.eye(n))
+
+
 @dataclass
 class Axis:
     """Everything one coordinate direction needs (sg.py:103-119, 181-210, 479-493)."""
     N: int
     L: float
+    kind: str = "chebyshev"
     x: np.ndarray = field(init=False)
     D: np.ndarray = field(init=False)
     D2: np.ndarray = field(init=False)
@@ -98,12 +128,17 @@ class Axis:
 
     def __post_init__(self):
         M = self.N + 1
-        xi = cgl_nodes(M)
+        if self.kind == "legendre":                            # basis/spectral.py:326-407
+            xi = lgl_nodes(M)
+            Dxi, wxi = legendre_diff_reference_interval(xi), lgl_weights(M)
+        else:
+            xi = cgl_nodes(M)
+            Dxi, wxi = cheb_diff_reference_interval(xi), clenshaw_curtis(M)
         self.x = 0.5 * (self.L - 0.0) * (xi + 1.0) + 0.0      # basis/spectral.py:498-502
-        self.D = (2.0 / (self.L - 0.0)) * cheb_diff_reference_interval(xi)  # :518-522
+        self.D = (2.0 / (self.L - 0.0)) * Dxi                  # :518-522
         self.D2 = self.D @ self.D                              # sg.py:192-193
         self.I = interp_inner_to_full(self.x[1:-1], self.x)    # sg.py:209-210
-        self.w = clenshaw_curtis(M) * (self.L - 0.0) / 2       # basis/spectral.py:538-541
+        self.w = wxi * (self.L - 0.0) / 2                      # basis/spectral.py:538-541
         self.hmin = float(np.min(np.diff(self.x)))             # sg.py:118-119
 
 
@@ -138,13 +173,17 @@ class OracleSG:
     """
 
     def __init__(self, N, Re, *, lid_velocity=1.0, Lx=1.0, Ly=1.0, CFL=1.5, beta_squared=5.0,
-                 corner_treatment="smoothing", corner_smoothing=0.15, stage_pressure=False):
+                 corner_treatment="smoothing", corner_smoothing=0.15, stage_pressure=False,
+                 basis_type="chebyshev"):
         self.N, self.Re = int(N), float(Re)
         self.U, self.Lx, self.Ly = float(lid_velocity), float(Lx), float(Ly)
         self.CFL, self.beta2 = float(CFL), float(beta_squared)
         self.stage_pressure = bool(stage_pressure)
-        self.ax = Axis(self.N, self.Lx)
-        self.ay = Axis(self.N, self.Ly)
+        kind = basis_type.lower()
+        if kind not in ("chebyshev", "legendre"):                # sg.py:52-63
+            raise ValueError(f"Unknown basis_type: {basis_type}. Use 'legendre' or 'chebyshev'")
+        self.ax = Axis(self.N, self.Lx, kind)
+        self.ay = Axis(self.N, self.Ly, kind)
         M = self.N + 1
         self.M, self.Mi = M, M - 2
         self.u_lid = lid_profile(self.ax.x, corner_treatment, corner_smoothing, self.U, self.Lx)

@@ -303,6 +303,29 @@ def g11_interp():
     np.savez_compressed(OUT / "g11_interp.npz", **out)
 
 
+def g12_legendre():
+    """basis_type='legendre' (sg.py:56-59): operators and short trajectories."""
+    out = {}
+    for N in (8, 16, 33):
+        s = make_sg(N, 100.0, basis_type="legendre")
+        out[f"N{N}_x"] = s.basis_x.nodes(N + 1)
+        out[f"N{N}_Dx"] = s.Dx_1d
+        out[f"N{N}_Dxx"] = s.Dxx_1d
+        out[f"N{N}_Interp_x"] = s.Interp_x
+        out[f"N{N}_w_x"] = s.w_x
+        out[f"N{N}_dx_min"] = np.array(s.dx_min)
+    for N, Re, K in ((16, 100.0, 60), (32, 400.0, 300)):
+        s = make_sg(N, Re, basis_type="legendre")
+        h = _run_steps(s, K)
+        tag = f"T{N}"
+        out[f"{tag}_u"], out[f"{tag}_v"], out[f"{tag}_p"] = s.arrays.u.copy(), s.arrays.v.copy(), s.arrays.p.copy()
+        for k, val in h.items():
+            out[f"{tag}_{k}"] = val
+    np.savez_compressed(OUT / "g12_legendre.npz", **out)
+    (OUT / "g12_legendre.json").write_text(json.dumps({"T16": dict(N=16, Re=100.0, K=60),
+                                                       "T32": dict(N=32, Re=400.0, K=300)}, indent=1))
+
+
 def make_fsg(N, Re, **kw):
     _install_shims()
     fsg = importlib.import_module("solvers.spectral.fsg")
@@ -358,7 +381,7 @@ def g8_fsg(full=False):
 
 GROUPS = {
     "G1": g1_operators, "G2": g2_lid, "G3": g3_single_stage, "G4": g4_trajectories,
-    "G4b": g4b_variants, "G7": g7_converged, "G11": g11_interp, "G8": g8_fsg,
+    "G4b": g4b_variants, "G7": g7_converged, "G11": g11_interp, "G8": g8_fsg, "G12": g12_legendre,
 }
 
 

@@ -129,6 +129,21 @@ def test_variants_vs_reference(golden_dir):
         assert rel(rec[:, 6], g[f"{name}_P"]) < 1e-9, name
 
 
+@pytest.mark.parametrize("tag", ["T16", "T32"])
+def test_legendre_basis_vs_reference(golden_dir, tag):
+    """basis_type='legendre': same device path, Legendre-Gauss-Lobatto operators from the host."""
+    g = np.load(golden_dir / "g12_legendre.npz")
+    c = json.loads((golden_dir / "g12_legendre.json").read_text())[tag]
+    s = make(c["N"], c["Re"], basis_type="legendre")
+    rec = s.run_iterations(c["K"])
+    for k, a in (("u", s.arrays.u), ("v", s.arrays.v), ("p", s.arrays.p)):
+        assert np.max(np.abs(a - g[f"{tag}_{k}"])) < 1e-11, k
+    assert rel(rec[:, 7], g[f"{tag}_dt"]) < 1e-12
+    assert rel(rec[:, 1:4], g[f"{tag}_res"]) < 1e-10
+    for col, k in ((4, "E"), (5, "Z"), (6, "P")):
+        assert rel(rec[:, col], g[f"{tag}_{k}"]) < 1e-9, k
+
+
 def test_graph_replay_equals_eager_launches():
     """hipGraph replays and plain launches must give bit-identical trajectories."""
     a = make(32, 100.0, graph_iters=8, check_every=64)

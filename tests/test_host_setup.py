@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import ldc_oracle as orc
-from solvers.spectral.basis.spectral import (ChebyshevLobattoBasis, clenshaw_curtis_weights,
+from solvers.spectral.basis.spectral import (ChebyshevLobattoBasis, LegendreLobattoBasis, clenshaw_curtis_weights,
                                               inner_to_full_interpolation)
 from solvers.spectral.basis.polynomial import spectral_interpolate
 from solvers.spectral.operators.corner import create_corner_treatment
@@ -27,6 +27,20 @@ def test_basis_matches_reference(golden_dir, N):
     assert rel(inner_to_full_interpolation(x[1:-1], x), g[f"N{N}_Interp_x"]) < 1e-13
     assert rel(b.quadrature_weights(N + 1), g[f"N{N}_w_x"]) < 1e-13
     assert abs(clenshaw_curtis_weights(N + 1).sum() - 2.0) < 1e-13
+
+
+@pytest.mark.parametrize("N", [8, 16, 33])
+def test_legendre_basis_matches_reference(golden_dir, N):
+    g = np.load(golden_dir / "g12_legendre.npz")
+    b = LegendreLobattoBasis(domain=(0.0, 1.0))
+    x = b.nodes(N + 1)
+    D = b.diff_matrix(x)
+    assert rel(x, g[f"N{N}_x"]) < 1e-15
+    assert rel(D, g[f"N{N}_Dx"]) < 1e-12
+    assert rel(D @ D, g[f"N{N}_Dxx"]) < 1e-11
+    assert rel(inner_to_full_interpolation(x[1:-1], x), g[f"N{N}_Interp_x"]) < 1e-12
+    assert rel(b.quadrature_weights(N + 1), g[f"N{N}_w_x"]) < 1e-13
+    assert abs(b.quadrature_weights(N + 1).sum() - 1.0) < 1e-13
 
 
 def test_lid_profiles_match_reference(golden_dir):

@@ -108,6 +108,33 @@ def test_trajectory(golden_dir, N, Re, K):
         assert abs(vm[str(key)] - ref) <= 1e-10 * max(abs(ref), 1.0), key
 
 
+@pytest.mark.parametrize("N", [8, 16, 33])
+def test_legendre_operators(golden_dir, N):
+    """basis_type='legendre' (sg.py:56-59): LGL nodes, D = Vx V^-1, LGL weights."""
+    g = np.load(golden_dir / "g12_legendre.npz")
+    ax = orc.Axis(N, 1.0, "legendre")
+    assert rel(ax.x, g[f"N{N}_x"]) < 1e-15
+    assert rel(ax.D, g[f"N{N}_Dx"]) < 1e-12
+    assert rel(ax.D2, g[f"N{N}_Dxx"]) < 1e-11
+    assert rel(ax.I, g[f"N{N}_Interp_x"]) < 1e-12
+    assert rel(ax.w, g[f"N{N}_w_x"]) < 1e-13
+    assert abs(ax.hmin - float(g[f"N{N}_dx_min"])) < 1e-15
+
+
+@pytest.mark.parametrize("tag", ["T16", "T32"])
+def test_legendre_trajectory(golden_dir, tag):
+    g = np.load(golden_dir / "g12_legendre.npz")
+    c = json.loads((golden_dir / "g12_legendre.json").read_text())[tag]
+    s = orc.OracleSG(c["N"], c["Re"], basis_type="legendre")
+    h = _run(s, c["K"])
+    for k, a in (("u", s.u), ("v", s.v), ("p", s.p)):
+        assert np.max(np.abs(a.ravel() - g[f"{tag}_{k}"])) < 1e-11, k
+    assert rel(h["dt"], g[f"{tag}_dt"]) < 1e-12
+    assert rel(h["res"], g[f"{tag}_res"]) < 1e-10
+    for k in ("E", "Z", "P"):
+        assert rel(h[k], g[f"{tag}_{k}"]) < 1e-10, k
+
+
 def test_variants(golden_dir):
     g = np.load(golden_dir / "g4b_variants.npz")
     meta = json.loads((golden_dir / "g4b_variants.json").read_text())
