@@ -94,8 +94,9 @@ def run_solver(cfg: dict, out_dir: Path, device: str = None) -> dict:
 
 
 def run_batch(cfgs: list, out_dirs: list, device: str = None) -> list:
-    """Several SG trials of equal N on one GPU, advanced by the same launches (solvers.spectral.batched)."""
-    from solvers.spectral.batched import BatchedSGSolver
+    """Several SG (or several FSG) trials of equal N on one GPU, advanced by the same launches
+    (solvers.spectral.batched)."""
+    from solvers.spectral.batched import BatchedFSGSolver, BatchedSGSolver
     nodes = []
     for cfg in cfgs:
         node = {k: v for k, v in cfg["solver"].items() if k != "_target_"}
@@ -103,7 +104,8 @@ def run_batch(cfgs: list, out_dirs: list, device: str = None) -> list:
             node["device"] = device
         nodes.append(node)
     t0 = time.perf_counter()
-    batch = BatchedSGSolver(nodes)
+    fsg = cfgs[0]["solver"]["_target_"].endswith("FSGSolver")
+    batch = (BatchedFSGSolver if fsg else BatchedSGSolver)(nodes)
     batch.solve()
     recs = [make_record(cfg, s, d, t0) for cfg, s, d in zip(cfgs, batch.solvers, out_dirs)]
     batch.close()
@@ -159,7 +161,7 @@ def main(argv=None) -> float | None:
     root_dir = time.strftime(str(root_tpl).replace("${now:", "").replace("}", ""), time.localtime())
     root_dir = Path(dist.all_gather_object(root_dir)[0])          # every rank uses rank 0's timestamp
 
-    SG = "solvers.spectral.sg.SGSolver"
+    SG, FSG = "solvers.spectral.sg.SGSolver", "solvers.spectral.fsg.FSGSolver"
     max_batch = int(os.environ.get("LDC_MAX_BATCH", stamp_cfg.get("hydra", {}).get("launcher", {}).get("batch_trials", 64)))
 
     def job_cfg(assignment, index):
@@ -171,7 +173,9 @@ def main(argv=None) -> float | None:
         """items: [(index, trial)] owned by this rank with one group key; SG trials of equal N share launches."""
         cfgs = [job_cfg(jobs[i], offset + i) for i, _ in items]
         out = []
-        if all(c["solver"]["_target_"] == SG for c in cfgs) and len(cfgs) > 1 and max_batch > 1:
+        targets = {c["solver"]["_target_"] for c in cfgs}
+        levels = {int(c["solver"].get("n_levels", 0)) for c in cfgs}
+        if targets in ({SG}, {FSG}) and len(levels) == 1 and len(cfgs) > 1 and max_batch > 1:
             for lo in range(0, len(cfgs), max_batch):
                 part = cfgs[lo: lo + max_batch]
                 log.info("batch of %d trials at N=%s on %s", len(part), part[0]["N"], device or "cuda:0")

@@ -34,6 +34,15 @@ class BatchedSGSolver:
         self._batch = None
         self._ws = None
 
+    @classmethod
+    def from_solvers(cls, solvers: list) -> "BatchedSGSolver":
+        """Batch existing solver objects of equal N (e.g. the levels of several FSG trials)."""
+        if not solvers or len({s.M for s in solvers}) != 1:
+            raise ValueError("need at least one solver, all of the same N")
+        self = cls.__new__(cls)
+        self.solvers, self._batch, self._ws = list(solvers), None, None
+        return self
+
     def __len__(self):
         return len(self.solvers)
 
@@ -66,6 +75,26 @@ class BatchedSGSolver:
         self.close_batch()
         for s in self.solvers:
             s.close()
+
+    def run_to_tolerance(self, tolerances, max_iter: int, diagnostics: bool = False) -> list:
+        """Every solver from its present state until ITS latch fires (or max_iter); returns per-solver
+        (latch, iterations, records).  Used by ``solve`` and by the batched FSG levels."""
+        self._ensure_batch(list(tolerances))
+        for s in self.solvers:
+            s.d["ctrl"].zero_()
+            s._prime()
+        cap = min(s.rec_cap for s in self.solvers)
+        chunk = max(1, min(int(self.solvers[0].params.check_every), cap))
+        blocks = [[] for _ in self.solvers]
+        state = [(0, 0)] * len(self.solvers)
+        it = 0
+        while it < max_iter and not all(d for d, _ in state):
+            k = 1 if any(s._edge_fix_pending for s in self.solvers) else min(chunk, max_iter - it)
+            for q, (rows, done, total) in enumerate(self._advance(k, diagnostics)):
+                blocks[q].append(rows)
+                state[q] = (done, total)
+            it += k
+        return [(d, t, np.concatenate(b, axis=0) if b else np.zeros((0, 8))) for (d, t), b in zip(state, blocks)]
 
     def __del__(self):
         try:
@@ -114,27 +143,77 @@ class BatchedSGSolver:
         p0 = self.solvers[0].params
         max_iter = p0.max_iterations if max_iter is None else max_iter
         diag = bool(p0.diagnostics)
-        self._ensure_batch([s.params.tolerance for s in self.solvers])
-        for s in self.solvers:
-            s.d["ctrl"].zero_()
-            s._prime()
-        cap = min(s.rec_cap for s in self.solvers)
-        chunk = max(1, min(int(p0.check_every), cap))
-        blocks = [[] for _ in self.solvers]
-        state = [(0, 0)] * len(self.solvers)            # (latch, total) per trial
         t0 = time.perf_counter()
-        it = 0
-        while it < max_iter and not all(d for d, _ in state):
-            k = 1 if any(s._edge_fix_pending for s in self.solvers) else min(chunk, max_iter - it)
-            res = self._advance(k, diag)
-            for q, (rows, done, total) in enumerate(res):
-                blocks[q].append(rows)
-                state[q] = (done, total)
-            it += k
+        out = self.run_to_tolerance([s.params.tolerance for s in self.solvers], max_iter, diag)
         wall = time.perf_counter() - t0
-        for q, s in enumerate(self.solvers):
-            hist = np.concatenate(blocks[q], axis=0) if blocks[q] else np.zeros((0, 8))
+        for s, (done, total, hist) in zip(self.solvers, out):
             s.history = hist
-            s._store_results(hist[WARMUP_ITERATIONS:], state[q][1], state[q][0] == 1, wall)
+            s._store_results(hist[WARMUP_ITERATIONS:], total, done == 1, wall)
         log.info("batched solve of %d trials finished in %.2f s", len(self.solvers), wall)
         return [s.metrics for s in self.solvers]
+
+
+class BatchedFSGSolver:
+    """Several FSG trials of equal N and hierarchy: level by level, the trials' level solvers share launches.
+
+    Same sequence per trial as ``FSGSolver.solve`` (reference multigrid/fsg.py:1053-1221): every level runs in
+    smoother mode to its own coarse tolerance with its own latch, a trial that diverges on a level stops there,
+    the others go on; prolongation stays per trial (two small products).  Results are bit-identical to
+    stand-alone FSG solves."""
+
+    def __init__(self, trials: list):
+        from .fsg import FSGSolver, hierarchy_orders
+        if not trials:
+            raise ValueError("BatchedFSGSolver needs at least one trial")
+        self.solvers = [FSGSolver(**t) for t in trials]
+        p0 = self.solvers[0].params
+        self.orders = hierarchy_orders(p0.nx, p0.n_levels)
+        for s in self.solvers:
+            if hierarchy_orders(s.params.nx, s.params.n_levels) != self.orders:
+                raise ValueError("all trials of a batch must share nx and the level hierarchy")
+
+    def __len__(self):
+        return len(self.solvers)
+
+    def close(self):
+        for s in self.solvers:
+            s.close()
+
+    def solve(self, max_iter: int = None):
+        t0 = time.perf_counter()
+        fines = self.solvers
+        for s in fines:
+            s._smoother_mode()
+        ladders = [[s._make_level(n) for n in self.orders[:-1]] + [s] for s in fines]
+        nlev = len(self.orders)
+        alive = list(range(len(fines)))
+        total = [0] * len(fines)
+        last = [0] * len(fines)                       # latch of the last level each trial ran
+        for idx in range(nlev):
+            group = [ladders[q][idx] for q in alive]
+            for q, lvl in zip(alive, group):
+                if idx == 0:
+                    lvl.reset_state()
+                else:
+                    fines[q]._prolongate(ladders[q][idx - 1], lvl)
+            tols = [fines[q].params.tolerance * fines[q].params.coarse_tolerance_factor ** (nlev - 1 - idx)
+                    for q in alive]
+            cap = min(fines[q].params.max_iterations for q in alive) if max_iter is None else max_iter
+            batch = BatchedSGSolver.from_solvers(group)
+            out = batch.run_to_tolerance(tols, cap, diagnostics=False)
+            batch.close_batch()
+            nxt = []
+            for q, (done, its, _) in zip(alive, out):
+                total[q] += its
+                last[q] = done
+                if done != 2:
+                    nxt.append(q)
+            log.info("batched FSG level %d (N=%d): %d trials, iterations %s", idx, self.orders[idx], len(alive),
+                     [o[1] for o in out])
+            alive = nxt
+        wall = time.perf_counter() - t0
+        for q, s in enumerate(fines):
+            for lvl in ladders[q][:-1]:
+                lvl.close()
+            s._finish(s.params.tolerance, total[q], last[q] == 1 and q in alive, wall)
+        return [s.metrics for s in fines]

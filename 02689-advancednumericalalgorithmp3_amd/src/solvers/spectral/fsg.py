@@ -90,6 +90,17 @@ class FSGSolver(SGSolver):
         v[:, -1] = 0.0
         fine.set_state_device(u, v, p)
 
+    def _finish(self, tolerance, total, converged, wall):
+        """One-point histories, like the reference (fsg.py:102-124)."""
+        res = self.residual_fields()
+        q = self.global_quantities()
+        row = np.zeros((1, 8))
+        row[0, REL] = tolerance if converged else tolerance * 10
+        row[0, RU], row[0, RV], row[0, RP] = (float(np.linalg.norm(res[k])) for k in ("R_u", "R_v", "R_p"))
+        row[0, EN], row[0, ZN], row[0, PN] = q["E"], q["Z"], q["P"]
+        self.history = row
+        self._store_results(row, total, converged, wall, with_diag=True)
+
     # ------------------------------------------------------------------ driver
     def solve(self, tolerance: float = None, max_iter: int = None):
         tolerance = self.params.tolerance if tolerance is None else tolerance
@@ -127,13 +138,5 @@ class FSGSolver(SGSolver):
             lvl.close()
         wall = time.perf_counter() - t0
         converged = bool(converged and not diverged)
-        # one-point histories, like the reference (fsg.py:102-124)
-        res = self.residual_fields()
-        q = self.global_quantities()
-        row = np.zeros((1, 8))
-        row[0, REL] = tolerance if converged else tolerance * 10
-        row[0, RU], row[0, RV], row[0, RP] = (float(np.linalg.norm(res[k])) for k in ("R_u", "R_v", "R_p"))
-        row[0, EN], row[0, ZN], row[0, PN] = q["E"], q["Z"], q["P"]
-        self.history = row
-        self._store_results(row, total, converged, wall, with_diag=True)
+        self._finish(tolerance, total, converged, wall)
         log.info("FSG completed in %.2fs: %d iterations, converged=%s", wall, total, converged)

@@ -61,3 +61,39 @@ def test_batch_rejects_mixed_sizes():
     from solvers.spectral.batched import BatchedSGSolver
     with pytest.raises(ValueError):
         BatchedSGSolver([kw(16, 100), kw(32, 100)])
+
+
+def fsg_kw(N, Re, cs=0.15, **extra):
+    d = kw(N, Re, cs, name="spectral_fsg", multigrid="fsg", n_levels=2, coarse_tolerance_factor=1.0,
+           prolongation_method="fft", restriction_method="fft", max_iterations=200000)
+    d.update(extra)
+    return d
+
+
+def test_batched_fsg_equals_individual_fsg_solves():
+    """Level by level the trials' smoothers share launches; every trial keeps its own latch per level.
+    Three-level hierarchy, different Re / lid regularisation / tolerances; one trial is capped by
+    max_iterations on every level.  Results equal the stand-alone FSG solves bit for bit."""
+    from solvers.spectral.batched import BatchedFSGSolver
+    from solvers.spectral.fsg import FSGSolver
+    trials = [fsg_kw(48, 100, 0.15, n_levels=3, tolerance=1e-4), fsg_kw(48, 200, 0.10, n_levels=3, tolerance=3e-4),
+              fsg_kw(48, 100, 0.30, n_levels=3, tolerance=1e-4, coarse_tolerance_factor=2.0),
+              fsg_kw(48, 50, 0.15, n_levels=3, tolerance=1e-5, CFL=1.0)]
+    b = BatchedFSGSolver(trials)
+    assert b.orders == [12, 24, 48]
+    ms = b.solve()
+    for t, s, m in zip(trials, b.solvers, ms):
+        one = FSGSolver(**t)
+        one.solve()
+        assert (m.converged, m.iterations) == (one.metrics.converged, one.metrics.iterations)
+        assert np.array_equal(s.fields.u, one.fields.u) and np.array_equal(s.fields.p, one.fields.p)
+        assert m.psi_min == one.metrics.psi_min and m.final_palinstrophy == one.metrics.final_palinstrophy
+        one.close()
+    assert all(m.converged for m in ms) and len({m.iterations for m in ms}) == 4
+    b.close()
+
+
+def test_batched_fsg_rejects_mixed_hierarchies():
+    from solvers.spectral.batched import BatchedFSGSolver
+    with pytest.raises(ValueError):
+        BatchedFSGSolver([fsg_kw(32, 100), fsg_kw(32, 100, n_levels=1)])
