@@ -21,18 +21,35 @@ from solvers.spectral.sg import SGSolver  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", default="64:100,64:400,64:1000")
 ap.add_argument("--max-iter", type=int, default=4_000_000)
+ap.add_argument("--tolerance", type=float, default=1e-6, help="1e-6 = the reference's default (conf/config.yaml:20)")
 ap.add_argument("--out", default="gpurun_out/ghia.json")
 a = ap.parse_args()
+import threading  # noqa: E402
+
+
+def heartbeat(stop, label):
+    """A long solve prints nothing by itself; gpurun takes 7 silent minutes for a hang."""
+    t0 = time.perf_counter()
+    while not stop.wait(60.0):
+        print(f"  ... {label}: {time.perf_counter() - t0:.0f} s", flush=True)
+
+
 out = []
+if Path(a.out).exists() and a.tolerance != 1e-6:
+    out = json.loads(Path(a.out).read_text())           # append to an earlier (partial) run
 for case in a.cases.split(","):
     N, Re = (int(x) for x in case.split(":"))
     s = SGSolver(name="spectral", Re=float(Re), nx=N, ny=N, basis_type="chebyshev", CFL=1.5, beta_squared=5.0,
-                 corner_treatment="smoothing", corner_smoothing=0.15, tolerance=1e-6, max_iterations=a.max_iter,
+                 corner_treatment="smoothing", corner_smoothing=0.15, tolerance=a.tolerance, max_iterations=a.max_iter,
                  check_every=4096, graph_iters=32)
     t0 = time.perf_counter()
+    stop = threading.Event()
+    hb = threading.Thread(target=heartbeat, args=(stop, case), daemon=True)
+    hb.start()
     s.solve()
+    stop.set()
     m = s.metrics
-    rec = dict(N=N, Re=Re, iterations=m.iterations, converged=m.converged, wall_time_seconds=m.wall_time_seconds,
+    rec = dict(N=N, Re=Re, tolerance=a.tolerance, iterations=m.iterations, converged=m.converged, wall_time_seconds=m.wall_time_seconds,
                steps_per_second=m.iterations / m.wall_time_seconds, total_seconds=time.perf_counter() - t0,
                final_residual=m.final_residual, psi_min=m.psi_min, psi_min_x=m.psi_min_x, psi_min_y=m.psi_min_y,
                omega_center=m.omega_center, psi_BR=m.psi_BR, psi_BL=m.psi_BL, E=m.final_energy, Z=m.final_enstrophy,
