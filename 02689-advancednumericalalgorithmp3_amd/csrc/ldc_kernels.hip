@@ -279,7 +279,7 @@ struct EdgeAcc {
 //          role 0: A0.B1 = Dx . VT (dv/dx)      role 1: A0.B0 = U . Dy (du/dy)
 // GP : the fifth contraction (grad p, or grad omega by o.x4)
 template <int VEL, bool GP>
-__device__ __forceinline__ void edge_group(EdgeAcc& e, const RoleFrags& f, const ExtraFrags& x, const RoleOps& o, int LD,
+__device__ __forceinline__ void edge_group(EdgeAcc& e, const RoleFrags& f, const ExtraFrags& x, const RoleOps& o,
                                            const double* erow, int n, int lane, bool rowE, bool colE, bool cornE) {
   // erow: this WAVE's pieces of the six rows of index M-1 (slots A0 A1 A2 B0 B1 B2) x its (at most four)
   // groups x 16 doubles, put into LDS by LDS-direct loads at kernel entry: no registers, no barrier, and
@@ -445,8 +445,8 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   const double adt = a.alpha * sload(a.scal + LDC_SCAL_DT);
 
   // ---- pointwise operands of the epilogue, issued now so that they land under the MFMAs ----------
-  // threads 0..255 own node (i, j) of the tile; in tiles of the last tile row / column threads 256..
-  // own the nodes of index M-1 next to it (kind 0: (M-1, c0+idx), 1: (r0+idx, M-1), 2: the corner)
+  // threads 0..255 own node (i, j) of the tile; in a tile with an index-(M-1) job threads 256.. own
+  // that job's nodes (kind 0: (M-1, c0+idx), 1: (r0+idx, M-1), 2: the corner)
   const int ti = 4 * (wv & 3) + (lane >> 4), tj = lane & 15;
   const bool owner = tid < 256;
   const int ekind = (tid - 256) >> 4, eidx = (tid - 256) & 15;
@@ -498,12 +498,12 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
     if (GP) load_extra(fx, o, LD, r0, c0, gk(n), lane);          // first: loads return in issue order
     load_role(fb, o, LD, r0, c0, gk(n + 1 < ng ? n + 1 : n), lane);   // clamped: harmless reload
     mfma_role<GP, NA>(fa, fx, acc, a.ablate, o.x4);
-    if (anyE) edge_group<VEL, GP>(ea, fa, fx, o, LD, erow, n, lane, rowE, colE, cornE);
+    if (anyE) edge_group<VEL, GP>(ea, fa, fx, o, erow, n, lane, rowE, colE, cornE);
     if (n + 1 < ng) {
       if (GP) load_extra(fx, o, LD, r0, c0, gk(n + 1), lane);
       load_role(fa, o, LD, r0, c0, gk(n + 2 < ng ? n + 2 : n + 1), lane);
       mfma_role<GP, NA>(fb, fx, acc, a.ablate, o.x4);
-      if (anyE) edge_group<VEL, GP>(ea, fb, fx, o, LD, erow, n + 1, lane, rowE, colE, cornE);
+      if (anyE) edge_group<VEL, GP>(ea, fb, fx, o, erow, n + 1, lane, rowE, colE, cornE);
     }
   }
 
@@ -1419,10 +1419,10 @@ int build_graph(ldc_solver* s, int with_diag) {
   int e = 0;
   for (int it = 0; it < s->iters_per_graph && e == 0; ++it) e = launch_iteration(s, with_diag, s->capture_stream);
   hipError_t ce = hipStreamEndCapture(s->capture_stream, &g);
-  if (e != 0) { if (g) hipGraphDestroy(g); return e; }
+  if (e != 0) { if (g) (void)hipGraphDestroy(g); return e; }
   if (ce != hipSuccess) return (int)ce;
   hipError_t ie = hipGraphInstantiate(&s->graph[with_diag], g, nullptr, nullptr, 0);
-  hipGraphDestroy(g);
+  (void)hipGraphDestroy(g);
   return (int)ie;
 }
 
@@ -1478,10 +1478,10 @@ int batch_build_graph(ldc_batch* b, int with_diag) {
   int e = 0;
   for (int it = 0; it < b->iters_per_graph && e == 0; ++it) e = batch_launch_iteration(b, with_diag, b->capture_stream);
   hipError_t ce = hipStreamEndCapture(b->capture_stream, &g);
-  if (e != 0) { if (g) hipGraphDestroy(g); return e; }
+  if (e != 0) { if (g) (void)hipGraphDestroy(g); return e; }
   if (ce != hipSuccess) return (int)ce;
   hipError_t ie = hipGraphInstantiate(&b->graph[with_diag], g, nullptr, nullptr, 0);
-  hipGraphDestroy(g);
+  (void)hipGraphDestroy(g);
   return (int)ie;
 }
 
@@ -1548,8 +1548,8 @@ int ldc_solver_create(const ldc_problem* d, ldc_solver** out) {
 
 int ldc_solver_destroy(ldc_solver* s) {
   if (!s) return LDC_E_STATE;
-  for (int q = 0; q < 2; ++q) if (s->graph[q]) hipGraphExecDestroy(s->graph[q]);
-  if (s->capture_stream) hipStreamDestroy(s->capture_stream);
+  for (int q = 0; q < 2; ++q) if (s->graph[q]) (void)hipGraphExecDestroy(s->graph[q]);
+  if (s->capture_stream) (void)hipStreamDestroy(s->capture_stream);
   delete s;
   return 0;
 }
@@ -1710,8 +1710,8 @@ int ldc_batch_create(ldc_solver* const* solvers, int n_trials, void* workspace, 
 
 int ldc_batch_destroy(ldc_batch* b) {
   if (!b) return LDC_E_STATE;
-  for (int q = 0; q < 2; ++q) if (b->graph[q]) hipGraphExecDestroy(b->graph[q]);
-  if (b->capture_stream) hipStreamDestroy(b->capture_stream);
+  for (int q = 0; q < 2; ++q) if (b->graph[q]) (void)hipGraphExecDestroy(b->graph[q]);
+  if (b->capture_stream) (void)hipStreamDestroy(b->capture_stream);
   delete b;
   return 0;
 }
