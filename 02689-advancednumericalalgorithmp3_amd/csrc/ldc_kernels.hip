@@ -1285,14 +1285,17 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
 
 template <bool GP, bool LAST, bool DUMP, bool BATCH, int DIAG>
 int launch_stage_kernel(const StageArgs& a, const StageArgs* arr, int nt, int nbatch, hipStream_t st) {
-  static bool attr_set = false;   // dynamic LDS above 64 KiB must be enabled once per kernel
+  static bool attr_set[64] = {};   // dynamic LDS above 64 KiB must be enabled once per kernel and device
   auto kern = stage_kernel<GP, LAST, DUMP, BATCH, DIAG>;
   constexpr size_t lds_bytes = StageLds<GP || DIAG == 2, GP || DIAG != 0 || LAST || DUMP>::BYTES;
   static_assert(lds_bytes <= kLdsLimit, "stage kernel LDS");
-  if (!attr_set) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return LDC_E_ARG;
+  if (!attr_set[dev]) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kLdsLimit));
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL(kern, dim3(nt, nbatch), dim3(kStageThreads), lds_bytes, st, a, arr);
   return (int)hipGetLastError();
