@@ -7,8 +7,10 @@
 //
 // Layout recap (include/ldc_hip.h): every array is LD x LD doubles, row-major, zero
 // padded, element [ix][iy]; each field has a transposed copy.  With that, EVERY product
-// on the path is of the "NT" form   C[i][j] = sum_k X[i][k] * Y[j][k]   and an MFMA
-// operand is one contiguous 32-byte run per lane (a full 128-byte line per 4 lanes):
+// on the path is of the "NT" form   C[i][j] = sum_k X[i][k] * Y[j][k].  The MFMA operands of
+// the iteration loop are read from PACKED TWINS (16 x 16 blocks in operand order, ldpk below):
+// a wave's fragment is then 2 KB contiguous; fetched from the row-major form (16 rows x 64 bytes
+// per instruction) the same bytes arrive 3.6x slower (profiles/r01_aql_probe.log).
 //
 //   d/dx  (Dx @ U)[i][j]   = sum_k Dx[i][k] * UT[j][k]
 //   d/dy  (U @ Dy^T)[i][j] = sum_k U [i][k] * Dy[j][k]
@@ -42,6 +44,12 @@ constexpr int kThreads = 256;
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ v4d ldfrag(const double* X, int ld, int r0, int k0, int lane) {
   return *reinterpret_cast<const v4d*>(X + (size_t)(r0 + (lane & 15)) * ld + k0 + 4 * (lane >> 4));
+}
+
+// The same fragment from a packed twin: block (R, G) = rows 16R.., k = 16G.. is 256 doubles in the order the
+// lanes consume them, lane l's four k-steps at 4 l (include/ldc_hip.h, Conventions).  NB = LD / 16.
+__device__ __forceinline__ v4d ldpk(const double* XK, int NB, int R, int G, int lane) {
+  return *reinterpret_cast<const v4d*>(XK + (((size_t)(R * NB + G) << 6) + lane) * 4);
 }
 
 // wave-uniform value that no thread of THIS launch writes: scalar load (waits on lgkmcnt, not on the
@@ -171,6 +179,11 @@ struct StageArgs {
   int ablate;                             // timing experiments only: 1 skip MFMAs, 2 skip operand loads,
                                           // 4 no stage-4 reduction, 8 no transposed stores, 16 no M-1 nodes, 32 no p store, 64 cycle stamps
   double* dump[11];
+  // packed twins (operand order, see ldpk): what the K loop reads / what the epilogue keeps in step
+  int NB;
+  const double *DxK, *D2xK, *DyK, *D2yK, *IxFK, *GxFK;
+  const double *UinK, *UinTK, *VinK, *VinTK, *T1TK, *T2TK;
+  double *UoutK, *UoutTK, *VoutK, *VoutTK, *PoutK, *WK, *WTK;
 };
 
 // slots of the stage-4 partial sums
@@ -202,7 +215,8 @@ __device__ __forceinline__ double quad_sum(double x) {
 //   role 1 (y-derivatives): A0 = U,  A1 = V   (rows I)   B0 = Dy, B1 = D2y (rows J)  A2 = IxF, B2 = T2T
 //        c00 = du/dy   c10 = dv/dy   c01 = d2u/dy2   c11 = d2v/dy2   c4 = dp/dy
 struct RoleOps {
-  const double *A0, *A1, *B0, *B1, *A2, *B2;
+  const double *A0, *A1, *B0, *B1, *A2, *B2;   // packed twins: the fragments of the K loop
+  const double* row[6];                        // the row-major forms, slots A0 A1 A2 B0 B1 B2 (rows of index M-1)
   int ablate;
   int role; // 0: x-derivative chains, 1: y-derivative chains
   int x4;   // fifth contraction: 0: A2.B2 (grad p)   1: A0.B2 (d omega/dx = Dx . WT)   2: A2.B0 (d omega/dy = W . Dy)
@@ -217,18 +231,19 @@ struct ExtraFrags {    // operands of the fifth contraction: single-buffered (lo
 
 // (timing switch `ablate & 2`: every lane reads element 0 instead -- same instructions, no operand traffic;
 //  a branch around the loads would make the compiler wait for them at the join)
-__device__ __forceinline__ void load_role(RoleFrags& f, const RoleOps& o, int LD, int r0, int c0, int k0, int lane) {
+// I, J: block row of the A / B operands; G: 16-k group
+__device__ __forceinline__ void load_role(RoleFrags& f, const RoleOps& o, int NB, int I, int J, int G, int lane) {
   const int keep = (o.ablate & 2) ? 0 : 1;
-  r0 *= keep; c0 *= keep; k0 *= keep; lane *= keep;
-  f.a0 = ldfrag(o.A0, LD, r0, k0, lane); f.a1 = ldfrag(o.A1, LD, r0, k0, lane);
-  f.b0 = ldfrag(o.B0, LD, c0, k0, lane); f.b1 = ldfrag(o.B1, LD, c0, k0, lane);
+  I *= keep; J *= keep; G *= keep; lane *= keep;
+  f.a0 = ldpk(o.A0, NB, I, G, lane); f.a1 = ldpk(o.A1, NB, I, G, lane);
+  f.b0 = ldpk(o.B0, NB, J, G, lane); f.b1 = ldpk(o.B1, NB, J, G, lane);
 }
 
-__device__ __forceinline__ void load_extra(ExtraFrags& x, const RoleOps& o, int LD, int r0, int c0, int k0, int lane) {
+__device__ __forceinline__ void load_extra(ExtraFrags& x, const RoleOps& o, int NB, int I, int J, int G, int lane) {
   const int keep = (o.ablate & 2) ? 0 : 1;
-  r0 *= keep; c0 *= keep; k0 *= keep; lane *= keep;
-  if (o.x4 != 1) x.a2 = ldfrag(o.A2, LD, r0, k0, lane);
-  if (o.x4 != 2) x.b2 = ldfrag(o.B2, LD, c0, k0, lane);
+  I *= keep; J *= keep; G *= keep; lane *= keep;
+  if (o.x4 != 1) x.a2 = ldpk(o.A2, NB, I, G, lane);
+  if (o.x4 != 2) x.b2 = ldpk(o.B2, NB, J, G, lane);
 }
 
 // LDS-direct 16-byte load: lane l's 16 bytes land at lds_dst + 16*l bytes (lds_dst wave-uniform);
@@ -360,8 +375,8 @@ struct StageLds {
   static constexpr int NA = GP ? 5 : 4;
   static constexpr int RED = kStageWaves * NA * 4 * 64;
   static constexpr int EDGE = RED;                         // [wave][15][16]
-  static constexpr int TILE = EDGE + kStageWaves * 15 * 16;  // 3 x 16 x 17
-  static constexpr int SCR = TILE + 3 * 16 * 17;           // kStageWaves * PS_N
+  static constexpr int TILE = EDGE + kStageWaves * 15 * 16;  // 4 x 16 x 17 (u, v, omega, p)
+  static constexpr int SCR = TILE + 4 * 16 * 17;           // kStageWaves * PS_N
   static constexpr int EROW = SCR + kStageWaves * PS_N;    // [wave][6 rows of index M-1][4 groups][16]
   static constexpr int TOTAL = EROW + (EDGES ? kStageWaves * kEdgeRowDoubles : 0);
   static constexpr size_t BYTES = sizeof(double) * TOTAL;
@@ -390,7 +405,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int role = wv >> 2, kq = wv & 3;
-  const int M = a.M, LD = a.LD, T = a.T, m1 = M - 1;
+  const int M = a.M, LD = a.LD, T = a.T, m1 = M - 1, NB = a.NB;
 
   int I, J;
   tile_of_block((int)blockIdx.x, T, I, J);
@@ -410,14 +425,18 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   o.ablate = a.ablate;
   o.role = role;
   o.x4 = (DIAG == 2) ? (role == 0 ? 1 : 2) : 0;
-  if (role == 0) { o.A0 = a.Dx; o.A1 = a.D2x; o.B0 = a.UinT; o.B1 = a.VinT; o.A2 = a.GxF; o.B2 = (DIAG == 2) ? a.WT : a.T1T; }
-  else           { o.A0 = a.Uin; o.A1 = a.Vin; o.B0 = a.Dy; o.B1 = a.D2y; o.A2 = (DIAG == 2) ? a.W : a.IxF; o.B2 = a.T2T; }
+  if (role == 0) {
+    o.A0 = a.DxK; o.A1 = a.D2xK; o.B0 = a.UinTK; o.B1 = a.VinTK; o.A2 = a.GxFK; o.B2 = (DIAG == 2) ? a.WTK : a.T1TK;
+    o.row[0] = a.Dx; o.row[1] = a.D2x; o.row[2] = a.GxF; o.row[3] = a.UinT; o.row[4] = a.VinT; o.row[5] = (DIAG == 2) ? a.WT : a.T1T;
+  } else {
+    o.A0 = a.UinK; o.A1 = a.VinK; o.B0 = a.DyK; o.B1 = a.D2yK; o.A2 = (DIAG == 2) ? a.WK : a.IxFK; o.B2 = a.T2TK;
+    o.row[0] = a.Uin; o.row[1] = a.Vin; o.row[2] = (DIAG == 2) ? a.W : a.IxF; o.row[3] = a.Dy; o.row[4] = a.D2y; o.row[5] = a.T2T;
+  }
 
   LDC_STAMP(0);
-  // this wave's K groups: kq, kq+4, ... (ng of them); group n starts at k = gk(n)
-  // this wave's K groups: kq, kq+4, ... (ng of them); group n starts at k = gk(n)
+  // this wave's K groups: kq, kq+4, ... (ng of them); group n is 16-k block gk(n)
   const int ng = (T - kq + 3) / 4;
-  auto gk = [&](int n) { return 16 * (kq + 4 * n); };
+  auto gk = [&](int n) { return kq + 4 * n; };
   double* erow = lds + L::EROW + wv * kEdgeRowDoubles;
 
   // ---- tiles with an index-(M-1) job: this wave's pieces of the six rows, LDS-direct, issued first
@@ -426,9 +445,9 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
     const size_t off = (size_t)m1 * LD + 16 * (kq + 4 * gi) + 4 * q + 2 * h;
     const bool live = (kq + 4 * gi) < T;
     const bool needA = rowE || cornE, needB = colE || cornE;
-    const double* s01 = sl ? o.A1 : o.A0;
-    const double* s23 = sl ? o.B0 : o.A2;
-    const double* s45 = sl ? o.B2 : o.B1;
+    const double* s01 = sl ? o.row[1] : o.row[0];
+    const double* s23 = sl ? o.row[3] : o.row[2];
+    const double* s45 = sl ? o.row[5] : o.row[4];
     if (live && needA && s01 != nullptr) dma16(s01 + off, erow);
     if (live && (sl ? needB : needA) && s23 != nullptr) dma16(s23 + off, erow + 128);
     if (live && needB && s45 != nullptr) dma16(s45 + off, erow + 256);
@@ -437,7 +456,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   // ---- first fragments in flight before anything else ------------------------------------
   RoleFrags fa, fb;
   ExtraFrags fx;
-  load_role(fa, o, LD, r0, c0, ng > 0 ? gk(0) : 0, lane);
+  load_role(fa, o, NB, I, J, ng > 0 ? gk(0) : 0, lane);
 
   // the latch and dt are read only now, behind the first operand loads (reads are harmless)
   if (!DUMP && sload(a.ctrl + LDC_CTRL_DONE) != 0) return;
@@ -491,17 +510,16 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   EdgeAcc ea;
 #pragma unroll
   for (int q = 0; q < 5; ++q) { ea.er[q] = 0.0; ea.ec[q] = 0.0; ea.ek[q] = 0.0; }
-  // Loads one group ahead (A/B ping-pong).  Deeper prefetch (a third group parked in LDS by LDS-direct
-  // loads) and per-tile rotation of the k order were measured and bought nothing: the loop is bound by
-  // the ~37 GB/s per CU at which the cold L2 delivers the 278 KB of operands, not by latency.
+  // Loads one group ahead (A/B ping-pong); with the packed twins one group ahead is enough (the probe delivers
+  // the whole 278 KB of a tile in ~1.9 us whatever the depth, profiles/r01_aql_probe.log).
   for (int n = 0; n < ng; n += 2) {
-    if (GP) load_extra(fx, o, LD, r0, c0, gk(n), lane);          // first: loads return in issue order
-    load_role(fb, o, LD, r0, c0, gk(n + 1 < ng ? n + 1 : n), lane);   // clamped: harmless reload
+    if (GP) load_extra(fx, o, NB, I, J, gk(n), lane);          // first: loads return in issue order
+    load_role(fb, o, NB, I, J, gk(n + 1 < ng ? n + 1 : n), lane);   // clamped: harmless reload
     mfma_role<GP, NA>(fa, fx, acc, a.ablate, o.x4);
     if (anyE) edge_group<VEL, GP>(ea, fa, fx, o, erow, n, lane, rowE, colE, cornE);
     if (n + 1 < ng) {
-      if (GP) load_extra(fx, o, LD, r0, c0, gk(n + 1), lane);
-      load_role(fa, o, LD, r0, c0, gk(n + 2 < ng ? n + 2 : n + 1), lane);
+      if (GP) load_extra(fx, o, NB, I, J, gk(n + 1), lane);
+      load_role(fa, o, NB, I, J, gk(n + 2 < ng ? n + 2 : n + 1), lane);
       mfma_role<GP, NA>(fb, fx, acc, a.ablate, o.x4);
       if (anyE) edge_group<VEL, GP>(ea, fb, fx, o, erow, n + 1, lane, rowE, colE, cornE);
     }
@@ -551,6 +569,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   double* tu = lds + L::TILE;
   double* tv = tu + 16 * 17;
   double* tw = tv + 16 * 17;
+  double* tp = tw + 16 * 17;
 
   if (owner || edge_thr) {
     // ---- one code path for tile nodes and for the nodes of index M-1 ------------------------------
@@ -611,7 +630,11 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
       else if (i == 0 || i == M - 1 || j == 0) { un = 0.0; vn = 0.0; }
       a.Uout[ij] = un;
       a.Vout[ij] = vn;
-      if (a.Pout != nullptr && !(a.ablate & 32)) a.Pout[ij] = interior ? (p0 + adt * Rp) : 0.0;
+      if (a.Pout != nullptr && !(a.ablate & 32)) {
+        const double pn = interior ? (p0 + adt * Rp) : 0.0;
+        a.Pout[ij] = pn;
+        tp[ti * 17 + tj] = pn;
+      }
       tu[ti * 17 + tj] = un;
       tv[ti * 17 + tj] = vn;
       if (LAST) {
@@ -646,6 +669,15 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
     a.UoutT[ot] = tu[tc * 17 + tr];
     a.VoutT[ot] = tv[tc * 17 + tr];
     if (DIAG == 1) a.WT[ot] = tw[tc * 17 + tr];
+    // packed twins of this tile: block (I, J) of the array, block (J, I) of its transposed copy; thread t
+    // stores double t of the 2-KB block = element (row pr, column pc) of the block
+    const int pl = tid >> 2, pr = pl & 15, pc = 4 * (pl >> 4) + (tid & 3);
+    const size_t kb = ((size_t)(I * NB + J) << 8) + tid, kbT = ((size_t)(J * NB + I) << 8) + tid;
+    const int e = pr * 17 + pc, eT = pc * 17 + pr;
+    a.UoutK[kb] = tu[e]; a.UoutTK[kbT] = tu[eT];
+    a.VoutK[kb] = tv[e]; a.VoutTK[kbT] = tv[eT];
+    if (DIAG == 1) { a.WK[kb] = tw[e]; a.WTK[kbT] = tw[eT]; }
+    if (a.Pout != nullptr && !(a.ablate & 32)) a.PoutK[kb] = tp[e];
   }
   if (DIAG != 0) {
     // one partial sum per work-group into the parity slab of the state this stage started from
@@ -823,6 +855,9 @@ struct PostArgs {
   long long stride;
   int ungated;     // stand-alone calls: always run
   int fin_block;   // index of the finalize block in this launch, or -1
+  int NB;
+  const double *PK, *IyFK, *GyFK;   // packed twins read by the T tiles
+  double *T1TK, *T2TK;              // packed twins they keep in step
   FinalArgs fin;
 };
 
@@ -858,9 +893,8 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
     const int r0 = 16 * I, c0 = 16 * J;
     v4d acc[2] = {(v4d){0, 0, 0, 0}, (v4d){0, 0, 0, 0}};
     for (int g = wv; g < T; g += kWaves) {
-      const int k0 = 16 * g;
-      const v4d fP = ldfrag(a.P, LD, r0, k0, lane);
-      const v4d fI = ldfrag(a.IyF, LD, c0, k0, lane), fG = ldfrag(a.GyF, LD, c0, k0, lane);
+      const v4d fP = ldpk(a.PK, a.NB, I, g, lane);
+      const v4d fI = ldpk(a.IyFK, a.NB, J, g, lane), fG = ldpk(a.GyFK, a.NB, J, g, lane);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         acc[0] = MFMA_F64(fP[s], fI[s], acc[0]);
@@ -881,6 +915,13 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
     const bool ok = (c0 + tr < M) && (r0 + tc < M);
     a.T1T[o] = ok ? t1[tc * 17 + tr] : 0.0;
     a.T2T[o] = ok ? t2[tc * 17 + tr] : 0.0;
+    {   // packed twins: block (J, I) of T1T / T2T, thread t stores double t (row pr, column pc of the block)
+      const int pl = tid >> 2, pr = pl & 15, pc = 4 * (pl >> 4) + (tid & 3);
+      const size_t kbT = ((size_t)(J * a.NB + I) << 8) + tid;
+      const bool okp = (c0 + pr < M) && (r0 + pc < M);
+      a.T1TK[kbT] = okp ? t1[pc * 17 + pr] : 0.0;
+      a.T2TK[kbT] = okp ? t2[pc * 17 + pr] : 0.0;
+    }
     return;
   }
   b -= nt;
@@ -1086,6 +1127,13 @@ __global__ __launch_bounds__(kThreads) void prime_kernel(const double* U, const 
 // ---------------------------------------------------------------------------------------
 // generic NT product (stream-function solve)
 // ---------------------------------------------------------------------------------------
+// packed twin of a row-major LD x LD array: one work-group per 16 x 16 block, thread t stores double t
+__global__ __launch_bounds__(kThreads) void pack_kernel(const double* src, double* dst, int LD) {
+  const int NB = LD >> 4, R = (int)blockIdx.x / NB, G = (int)blockIdx.x % NB, t = threadIdx.x;
+  const int l = t >> 2, r = l & 15, c = 4 * (l >> 4) + (t & 3);
+  dst[((size_t)blockIdx.x << 8) + t] = src[(size_t)(16 * R + r) * LD + 16 * G + c];
+}
+
 struct GemmArgs {
   const double *A, *B;
   double* C;
@@ -1274,11 +1322,23 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
                        {p.UA, p.UAT, p.VA, p.VAT}, {p.U, p.UT, p.V, p.VT}};
   a.Uin = in[k][0]; a.UinT = in[k][1]; a.Vin = in[k][2]; a.VinT = in[k][3];
   a.Uout = out[k][0]; a.UoutT = out[k][1]; a.Vout = out[k][2]; a.VoutT = out[k][3];
+  // the same ping-pong for the packed twins
+  a.NB = p.LD / 16;
+  a.DxK = p.DxK; a.D2xK = p.D2xK; a.DyK = p.DyK; a.D2yK = p.D2yK; a.IxFK = p.IxFK; a.GxFK = p.GxFK;
+  a.T1TK = p.T1TK; a.T2TK = p.T2TK; a.WK = p.WK; a.WTK = p.WTK;
+  const double *ink[4][4] = {{p.UK, p.UTK, p.VK, p.VTK}, {p.UAK, p.UATK, p.VAK, p.VATK},
+                             {p.UBK, p.UBTK, p.VBK, p.VBTK}, {p.UAK, p.UATK, p.VAK, p.VATK}};
+  double* outk[4][4] = {{p.UAK, p.UATK, p.VAK, p.VATK}, {p.UBK, p.UBTK, p.VBK, p.VBTK},
+                        {p.UAK, p.UATK, p.VAK, p.VATK}, {p.UK, p.UTK, p.VK, p.VTK}};
+  a.UinK = ink[k][0]; a.UinTK = ink[k][1]; a.VinK = ink[k][2]; a.VinTK = ink[k][3];
+  a.UoutK = outk[k][0]; a.UoutTK = outk[k][1]; a.VoutK = outk[k][2]; a.VoutTK = outk[k][3];
   if (p.stage_pressure) {
     double* pout[4] = {p.PA, p.PB, p.PA, p.P};   // FSG smoother: p_stage is consumed by the next stage
-    a.Pout = pout[k];
+    double* poutk[4] = {p.PAK, p.PBK, p.PAK, p.PK};
+    a.Pout = pout[k]; a.PoutK = poutk[k];
   } else {
     a.Pout = (k == 3) ? p.P : nullptr;           // SG never consumes the stage pressures (quirk Q1)
+    a.PoutK = (k == 3) ? p.PK : nullptr;
   }
   return a;
 }
@@ -1345,6 +1405,9 @@ PostArgs make_post_args(const ldc_solver* s, const double* P, int do_omega, int 
   a.M = p.M; a.LD = p.LD; a.T = p.T; a.tail = p.tail; a.do_omega = do_omega;
   a.Dx = p.Dx; a.Dy = p.Dy; a.IyF = p.IyF; a.GyF = p.GyF;
   a.U = p.U; a.V = p.V; a.VT = p.VT; a.P = P;
+  a.NB = p.LD / 16;
+  a.PK = (P == p.PA) ? p.PAK : (P == p.PB) ? p.PBK : p.PK;
+  a.IyFK = p.IyFK; a.GyFK = p.GyFK; a.T1TK = p.T1TK; a.T2TK = p.T2TK;
   a.T1T = p.T1T; a.T2T = p.T2T; a.W = p.W; a.WT = p.WT; a.wx = p.wx; a.wy = p.wy;
   a.ctrl = p.ctrl; a.partZ0 = p.partials + p.partials_stride; a.stride = p.partials_stride;
   a.ungated = loop ? 0 : 1;
@@ -1527,11 +1590,14 @@ int ldc_solver_create(const ldc_problem* d, ldc_solver** out) {
   if (!lay_a && !lay_b) return LDC_E_ARG;
   if (d->rec_cap < 1 || (d->stage_pressure != 0 && d->stage_pressure != 1)) return LDC_E_ARG;
   if (d->tail && d->T > 16) return LDC_E_ARG;   // the index-(M-1) jobs stage four groups per wave
-  if (d->stage_pressure && (!d->PA || !d->PB)) return LDC_E_ARG;
+  if (d->stage_pressure && (!d->PA || !d->PB || !d->PAK || !d->PBK)) return LDC_E_ARG;
   const void* req[] = {d->Dx, d->D2x, d->Dy, d->D2y, d->IxF, d->GxF, d->IyF, d->GyF, d->wx, d->wy, d->ulid,
                        d->DxL, d->D2xL, d->DyL, d->D2yL,
                        d->U, d->UT, d->V, d->VT, d->P, d->UA, d->UAT, d->VA, d->VAT, d->UB, d->UBT, d->VB,
-                       d->VBT, d->T1T, d->T2T, d->PX, d->PY, d->W, d->WT, d->partials, d->scal, d->ctrl, d->rec};
+                       d->VBT, d->T1T, d->T2T, d->PX, d->PY, d->W, d->WT, d->partials, d->scal, d->ctrl, d->rec,
+                       d->DxK, d->D2xK, d->DyK, d->D2yK, d->IxFK, d->GxFK, d->IyFK, d->GyFK,
+                       d->UK, d->UTK, d->VK, d->VTK, d->PK, d->UAK, d->UATK, d->VAK, d->VATK,
+                       d->UBK, d->UBTK, d->VBK, d->VBTK, d->T1TK, d->T2TK, d->WK, d->WTK};
   for (const void* q : req) if (bad_ptr(q)) return LDC_E_ARG;
   ldc_solver* s = new (std::nothrow) ldc_solver;
   if (!s) return LDC_E_STATE;
@@ -1734,6 +1800,12 @@ int ldc_batch_enqueue(ldc_batch* b, int n_iters, int with_diag, void* stream) {
   }
   for (; left > 0; --left) { int e = batch_launch_iteration(b, with_diag, st); if (e) return e; }
   return (with_diag && n_iters > 0) ? batch_closing_diagnostics(b, st) : 0;
+}
+
+int ldc_pack(const double* src, double* dst, int LD, void* stream) {
+  if (!src || !dst || src == dst || LD < 16 || LD % 16 != 0) return LDC_E_ARG;
+  hipLaunchKernelGGL(pack_kernel, dim3((LD / 16) * (LD / 16)), dim3(kThreads), 0, as_stream(stream), src, dst, LD);
+  return (int)hipGetLastError();
 }
 
 int ldc_residual_debug(ldc_solver* s, int which, double* const out[11], void* stream) {

@@ -34,6 +34,11 @@ class Problem(C.Structure):
             "UA", "UAT", "VA", "VAT", "PA",
             "UB", "UBT", "VB", "VBT", "PB",
             "T1T", "T2T", "PX", "PY", "W", "WT",
+            "DxK", "D2xK", "DyK", "D2yK", "IxFK", "GxFK", "IyFK", "GyFK",
+            "UK", "UTK", "VK", "VTK", "PK",
+            "UAK", "UATK", "VAK", "VATK", "PAK",
+            "UBK", "UBTK", "VBK", "VBTK", "PBK",
+            "T1TK", "T2TK", "WK", "WTK",
             "partials")]
         + [("partials_stride", C.c_int64)]
         + [(n, _dp) for n in ("scal", "ctrl", "rec")]
@@ -83,6 +88,7 @@ def lib() -> C.CDLL:
     L.ldc_gemm_nt.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
     L.ldc_poisson_fastdiag.argtypes = [_dp] * 10 + [C.c_int, C.c_int, _dp]
     L.ldc_vortex_extrema.argtypes = [_dp, _dp, _dp, _dp, C.c_int, C.c_int, _dp, _dp, _dp]
+    L.ldc_pack.argtypes = [_dp, _dp, C.c_int, _dp]
     L.ldc_debug_ablate.argtypes = [_dp, C.c_int]
     L.ldc_debug_stamps.argtypes = [_dp, C.c_void_p]
     L.ldc_mfma_selftest.argtypes = [_dp, _dp, _dp, _dp]
@@ -101,6 +107,7 @@ EXPORTS = (
     "ldc_solver_enqueue", "ldc_solver_set_graph_iters", "ldc_residual_debug", "ldc_gemm_nt",
     "ldc_batch_workspace_bytes", "ldc_batch_create", "ldc_batch_destroy", "ldc_batch_enqueue",
     "ldc_poisson_fastdiag", "ldc_vortex_extrema", "ldc_mfma_selftest", "ldc_mfma_peak", "ldc_debug_ablate", "ldc_debug_stamps",
+    "ldc_pack",
 )
 
 

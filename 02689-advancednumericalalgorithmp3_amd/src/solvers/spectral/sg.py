@@ -26,7 +26,13 @@ log = logging.getLogger(__name__)
 _MAT_NAMES = ("Dx", "D2x", "Dy", "D2y", "IxF", "GxF", "IyF", "GyF",
               "U", "UT", "V", "VT", "P", "UA", "UAT", "VA", "VAT", "PA",
               "UB", "UBT", "VB", "VBT", "PB", "T1T", "T2T", "PX", "PY", "W", "WT",
-              "S0", "S1", "S2", "S3", "S4", "S5", "S6", "S7", "S8", "S9", "S10")   # S*: scratch
+              "S0", "S1", "S2", "S3", "S4", "S5", "S6", "S7", "S8", "S9", "S10",   # S*: scratch
+              # packed twins (include/ldc_hip.h, Conventions): what the MFMA operand loads of the loop read
+              "DxK", "D2xK", "DyK", "D2yK", "IxFK", "GxFK", "IyFK", "GyFK",
+              "UK", "UTK", "VK", "VTK", "PK", "UAK", "UATK", "VAK", "VATK", "PAK",
+              "UBK", "UBTK", "VBK", "VBTK", "PBK", "T1TK", "T2TK", "WK", "WTK")
+_PACKED_OPERATORS = ("Dx", "D2x", "Dy", "D2y", "IxF", "GxF", "IyF", "GyF")
+_PACKED_STATE = ("U", "UT", "V", "VT", "P", "UA", "UAT", "VA", "VAT", "PA", "UB", "UBT", "VB", "VBT", "PB")
 _DEBUG_KEYS = ("du_dx", "du_dy", "dv_dx", "dv_dy", "lap_u", "lap_v", "dp_dx", "dp_dy", "R_u", "R_v", "R_p")
 
 
@@ -155,12 +161,20 @@ class SGSolver(LidDrivenCavitySolver):
         for name, a in (("Dx", self.Dx_1d), ("D2x", self.Dxx_1d), ("Dy", self.Dy_1d), ("D2y", self.Dyy_1d),
                         ("IxF", IxF), ("GxF", self.Dx_1d @ IxF), ("IyF", IyF), ("GyF", self.Dy_1d @ IyF)):
             up(name, a)
+        self._pack(_PACKED_OPERATORS)
         for name, v in (("wx", self.w_x), ("wy", self.w_y), ("ulid", self.u_lid),
                         ("x", self.x_nodes), ("y", self.y_nodes),
                         ("DxL", self.Dx_1d[:, -1]), ("D2xL", self.Dxx_1d[:, -1]),
                         ("DyL", self.Dy_1d[:, -1]), ("D2yL", self.Dyy_1d[:, -1])):
             pad = np.zeros(LD); pad[:M] = v
             self.d[name].copy_(torch.from_numpy(pad))
+
+    def _pack(self, names):
+        """Bring the packed twins of the named row-major arrays up to date (host-side edits only:
+        the kernels keep both forms in step themselves)."""
+        for n in names:
+            L.check(L.lib().ldc_pack(self.d[n].data_ptr(), self.d[n + "K"].data_ptr(), self.LD, L.stream_ptr()),
+                    "ldc_pack")
 
     # ------------------------------------------------------------------ state transfer
     def _download_full(self, name: str) -> np.ndarray:
@@ -199,10 +213,13 @@ class SGSolver(LidDrivenCavitySolver):
             self._write_boundary_edges(("UA", "UAT", "VA", "VAT"))
             self._write_boundary_edges(("UB", "UBT", "VB", "VBT"))
             self._edge_fix_pending = True
+        self._pack(_PACKED_STATE)
         self._primed = False
 
     def _write_boundary_edges(self, names):
-        """Boundary values on the row/column of index M-1 of (U, UT, V, VT)-like arrays."""
+        """Boundary values on the row/column of index M-1 of (U, UT, V, VT)-like arrays (tail layout only:
+        index M-1 = 16 T lies in block row/column T, which no MFMA operand load reads, so the packed
+        twins need no update)."""
         m1, M = self.M - 1, self.M
         U, UT, V, VT = (self.d[n] for n in names)
         lid = self.d["ulid"][:M]

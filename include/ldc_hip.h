@@ -16,7 +16,14 @@
  *  - all 2-D arrays are row-major LD x LD doubles, zero padded, element [ix][iy]
  *    (reference sg.py:108, indexing="ij"); LD is a multiple of 16 and >= 16*T + 16.
  *  - "transposed copy" XT means XT[iy][ix] = X[ix][iy]; the kernels keep both so that
- *    every MFMA operand is a contiguous 32-byte run per lane.
+ *    every product on the path is of the NT form C[i][j] = sum_k X[i][k] Y[j][k].
+ *  - "packed twin" XK: the same LD x LD values as X, stored as (LD/16)^2 blocks of 16 x 16 doubles,
+ *    block (R, G) (rows 16R.., columns 16G..) at XK + (R*(LD/16) + G)*256, and inside a block in the
+ *    order one f64 MFMA operand load consumes them: element (r, 4c+s) at (16c + r)*4 + s.  A wave's
+ *    operand fragment is then 2 KB contiguous (lane l reads 32 bytes at 32 l); read from the row-major
+ *    array the same fragment is 16 rows x 64 bytes per instruction and is delivered 3.6x slower
+ *    (profiles/r01_aql_probe.log).  Every array that feeds the MFMAs of the iteration loop has a
+ *    twin; the kernels keep both forms in step, the host packs what it uploads (ldc_pack).
  *  - functions return 0 on success, a negative LDC_E_* code for argument errors or a
  *    positive hipError_t.  Nothing throws; nothing synchronises unless stated.
  *  - `stream` is a hipStream_t passed as void*.
@@ -31,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LDC_ABI_VERSION 1
+#define LDC_ABI_VERSION 2
 
 #define LDC_E_ARG      (-1)  /* null pointer / inconsistent geometry */
 #define LDC_E_STATE    (-2)  /* handle not valid for the call */
@@ -105,6 +112,13 @@ typedef struct ldc_problem {
   double *T1T, *T2T, *PX, *PY;
   /* diagnostics: vorticity and its transpose                                           */
   double *W, *WT;
+  /* packed twins (see Conventions) of the operators, the state, the stage buffers, the pressure
+     transforms and the vorticity                                                        */
+  const double *DxK, *D2xK, *DyK, *D2yK, *IxFK, *GxFK, *IyFK, *GyFK;
+  double *UK, *UTK, *VK, *VTK, *PK;
+  double *UAK, *UATK, *VAK, *VATK, *PAK;
+  double *UBK, *UBTK, *VBK, *VBTK, *PBK;
+  double *T1TK, *T2TK, *WK, *WTK;
   /* reductions / control                                                               */
   double  *partials;  /* 5 slabs of partials_stride doubles: stage 4 | Z parity 0,1 | P parity 0,1 */
   int64_t  partials_stride; /* doubles between slabs                                    */
@@ -164,6 +178,10 @@ int ldc_batch_create(ldc_solver *const *solvers, int n_trials, void *workspace, 
 int ldc_batch_destroy(ldc_batch *b);
 /* n_iters iterations of base.py:243-313 for every trial that is not latched yet                 */
 int ldc_batch_enqueue(ldc_batch *b, int n_iters, int with_diagnostics, void *stream);
+
+/* packed twin of a row-major LD x LD array (both device pointers, src != dst); used by the host   */
+/* after it uploads or edits operators / state                                                     */
+int ldc_pack(const double *src, double *dst, int LD, void *stream);
 
 /* debugging aid for parity tests: one residual evaluation of state `which`              */
 /* (0: U/V, 1: UA/VA, 2: UB/VB) with every intermediate written to LD x LD arrays:       */
