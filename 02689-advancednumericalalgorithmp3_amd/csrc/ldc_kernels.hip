@@ -52,6 +52,23 @@ __device__ __forceinline__ v4d ldpk(const double* XK, int NB, int R, int G, int 
   return *reinterpret_cast<const v4d*>(XK + (((size_t)(R * NB + G) << 6) + lane) * 4);
 }
 
+// Store of state that only LATER launches read: agent-scope write-through (global_store ... sc1).  The bytes
+// leave the XCD's L2 while the other tiles still compute instead of at the end-of-kernel write-back
+// (4-7 MB dirty per stage launch): -2.1 us per iteration at N=256; non-temporal stores bought nothing.
+// (LDC_STORE_MODE 0 = plain, 2 = non-temporal: kept for A/B timing with tools/ab_iter.py)
+#ifndef LDC_STORE_MODE
+#define LDC_STORE_MODE 1
+#endif
+__device__ __forceinline__ void st_out(double* p, double v) {
+#if LDC_STORE_MODE == 1
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif LDC_STORE_MODE == 2
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 // wave-uniform value that no thread of THIS launch writes: scalar load (waits on lgkmcnt, not on the
 // vector-memory queue behind which the operand prefetch sits)
 template <typename T>
@@ -597,14 +614,14 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
       px = valid ? C(0, 4) : 0.0;   // row M-1 of T1T/T2T meets a zero column of GxF/IxF: no completion term
       py = valid ? C(1, 4) : 0.0;
       if (!DUMP) {
-        a.PX[ij] = px; a.PY[ij] = py;
-        if (colnode) { a.PX[(size_t)M * LD + i] = px; a.PY[(size_t)M * LD + i] = py; }
+        st_out(a.PX + ij, px); st_out(a.PY + ij, py);
+        if (colnode) { st_out(a.PX + (size_t)M * LD + i, px); st_out(a.PY + (size_t)M * LD + i, py); }
       }
     }
     if (DIAG == 1) {
       const double w = valid ? (vx - uy) : 0.0;          // sg.py:510-522 on phi^(n+1) (= this stage's input)
-      a.W[ij] = w;
-      if (owner) tw[ti * 17 + tj] = w; else a.WT[(size_t)j * LD + i] = w;
+      st_out(a.W + ij, w);
+      if (owner) tw[ti * 17 + tj] = w; else st_out(a.WT + (size_t)j * LD + i, w);
       dsum = valid ? wq * w * w : 0.0;
     }
     if (DIAG == 2) {
@@ -628,11 +645,11 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
       if (!valid) { un = 0.0; vn = 0.0; }
       else if (j == M - 1) { un = lidv; vn = 0.0; }
       else if (i == 0 || i == M - 1 || j == 0) { un = 0.0; vn = 0.0; }
-      a.Uout[ij] = un;
-      a.Vout[ij] = vn;
+      st_out(a.Uout + ij, un);
+      st_out(a.Vout + ij, vn);
       if (a.Pout != nullptr && !(a.ablate & 32)) {
         const double pn = interior ? (p0 + adt * Rp) : 0.0;
-        a.Pout[ij] = pn;
+        st_out(a.Pout + ij, pn);
         tp[ti * 17 + tj] = pn;
       }
       tu[ti * 17 + tj] = un;
@@ -666,18 +683,18 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   if (owner && !(a.ablate & 8)) {
     const int tr = tid >> 4, tc = tid & 15;   // write UT[c0+tr][r0+tc] = tile[tc][tr]
     const size_t ot = (size_t)(c0 + tr) * LD + r0 + tc;
-    a.UoutT[ot] = tu[tc * 17 + tr];
-    a.VoutT[ot] = tv[tc * 17 + tr];
-    if (DIAG == 1) a.WT[ot] = tw[tc * 17 + tr];
+    st_out(a.UoutT + ot, tu[tc * 17 + tr]);
+    st_out(a.VoutT + ot, tv[tc * 17 + tr]);
+    if (DIAG == 1) st_out(a.WT + ot, tw[tc * 17 + tr]);
     // packed twins of this tile: block (I, J) of the array, block (J, I) of its transposed copy; thread t
     // stores double t of the 2-KB block = element (row pr, column pc) of the block
     const int pl = tid >> 2, pr = pl & 15, pc = 4 * (pl >> 4) + (tid & 3);
     const size_t kb = ((size_t)(I * NB + J) << 8) + tid, kbT = ((size_t)(J * NB + I) << 8) + tid;
     const int e = pr * 17 + pc, eT = pc * 17 + pr;
-    a.UoutK[kb] = tu[e]; a.UoutTK[kbT] = tu[eT];
-    a.VoutK[kb] = tv[e]; a.VoutTK[kbT] = tv[eT];
-    if (DIAG == 1) { a.WK[kb] = tw[e]; a.WTK[kbT] = tw[eT]; }
-    if (a.Pout != nullptr && !(a.ablate & 32)) a.PoutK[kb] = tp[e];
+    st_out(a.UoutK + kb, tu[e]); st_out(a.UoutTK + kbT, tu[eT]);
+    st_out(a.VoutK + kb, tv[e]); st_out(a.VoutTK + kbT, tv[eT]);
+    if (DIAG == 1) { st_out(a.WK + kb, tw[e]); st_out(a.WTK + kbT, tw[eT]); }
+    if (a.Pout != nullptr && !(a.ablate & 32)) st_out(a.PoutK + kb, tp[e]);
   }
   if (DIAG != 0) {
     // one partial sum per work-group into the parity slab of the state this stage started from
@@ -913,14 +930,14 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
     const int tr = tid >> 4, tc = tid & 15;
     const size_t o = (size_t)(c0 + tr) * LD + r0 + tc;
     const bool ok = (c0 + tr < M) && (r0 + tc < M);
-    a.T1T[o] = ok ? t1[tc * 17 + tr] : 0.0;
-    a.T2T[o] = ok ? t2[tc * 17 + tr] : 0.0;
+    st_out(a.T1T + o, ok ? t1[tc * 17 + tr] : 0.0);
+    st_out(a.T2T + o, ok ? t2[tc * 17 + tr] : 0.0);
     {   // packed twins: block (J, I) of T1T / T2T, thread t stores double t (row pr, column pc of the block)
       const int pl = tid >> 2, pr = pl & 15, pc = 4 * (pl >> 4) + (tid & 3);
       const size_t kbT = ((size_t)(J * a.NB + I) << 8) + tid;
       const bool okp = (c0 + pr < M) && (r0 + pc < M);
-      a.T1TK[kbT] = okp ? t1[pc * 17 + pr] : 0.0;
-      a.T2TK[kbT] = okp ? t2[pc * 17 + pr] : 0.0;
+      st_out(a.T1TK + kbT, okp ? t1[pc * 17 + pr] : 0.0);
+      st_out(a.T2TK + kbT, okp ? t2[pc * 17 + pr] : 0.0);
     }
     return;
   }
@@ -933,7 +950,7 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
       const double* pk = a.P + (size_t)k * LD;
       const double t1 = dot_rows(pk, a.IyF + (size_t)m1 * LD, M, lane);
       const double t2 = dot_rows(pk, a.GyF + (size_t)m1 * LD, M, lane);
-      if (lane == 0) { a.T1T[(size_t)m1 * LD + k] = t1; a.T2T[(size_t)m1 * LD + k] = t2; }
+      if (lane == 0) { st_out(a.T1T + (size_t)m1 * LD + k, t1); st_out(a.T2T + (size_t)m1 * LD + k, t2); }
     }
     return;
   }
