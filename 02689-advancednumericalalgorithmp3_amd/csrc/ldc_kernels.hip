@@ -159,17 +159,17 @@ __device__ __forceinline__ void block_reduce_store(double (&sums)[NV], double (&
 // blockIdx -> tile.  Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an
 // L2), so give each XCD a compact (T/2 x T/4 when T%8==0) patch of tiles: the operand
 // panels it re-reads then stay in its own L2.  Pure speed; any bijection is correct.
+// Branch-free on purpose: a branch here splits the kernel's entry block, and the scalar loads of the
+// kernel arguments used after it are then issued one cold miss after the other instead of together.
 __device__ __forceinline__ void tile_of_block(int b, int T, int& I, int& J) {
-  if ((T & 7) == 0) {
-    const int xcd = b & 7, loc = b >> 3;          // loc in [0, T*T/8)
-    const int pr = T / 4, pc = T / 2;             // patch rows/cols: 4 x 2 patches
-    const int pI = xcd >> 1, pJ = xcd & 1;
-    I = pI * pr + loc / pc;
-    J = pJ * pc + loc % pc;
-  } else {
-    I = b / T;
-    J = b % T;
-  }
+  const bool patched = (T & 7) == 0;
+  const int xcd = b & 7, loc = b >> 3;          // loc in [0, T*T/8)
+  const int pr = T >> 2, pc = patched ? (T >> 1) : 1;   // patch rows/cols: 4 x 2 patches
+  const int pI = xcd >> 1, pJ = xcd & 1;
+  const int Ip = pI * pr + loc / pc, Jp = pJ * pc + loc % pc;
+  const int Iq = b / T, Jq = b - Iq * T;
+  I = patched ? Ip : Iq;
+  J = patched ? Jp : Jq;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -211,8 +211,11 @@ static_assert(PS_NSUM == 8, "stage-4 reduction assigns one wave per sum");
 constexpr int kStageWaves = 8;                 // 2 waves per SIMD: needed to saturate the f64 MFMA pipe
 constexpr int kStageThreads = 64 * kStageWaves;
 // timing experiments (ldc_debug_stamps): cycle stamps per wave at fixed points of the stage kernel
-#define LDC_STAMP(k) do { if ((a.ablate & 64) && lane == 0) \
-  a.dump[0][((size_t)blockIdx.x * kStageWaves + wv) * 8 + (k)] = (double)__builtin_amdgcn_s_memtime(); } while (0)
+// (point 0 = kernel entry is taken unconditionally into t_entry and stored with point 1: a conditional store
+//  in the prologue would split the entry block, see tile_of_block)
+#define LDC_STAMP(k) do { if ((a.ablate & 64) && lane == 0) { \
+  double* st_ = a.dump[0] + ((size_t)blockIdx.x * kStageWaves + wv) * 8; \
+  st_[k] = (double)__builtin_amdgcn_s_memtime(); if ((k) == 1) st_[0] = (double)t_entry; } } while (0)
 constexpr int kEdgeRowDoubles = 6 * 4 * 16;    // per wave: 6 rows of index M-1 x 4 groups x 16 (tail needs T <= 16)
 constexpr size_t kLdsLimit = 160 * 1024;
 
@@ -419,6 +422,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   constexpr int NA = L::NA;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* red = lds;
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int role = wv >> 2, kq = wv & 3;
@@ -450,13 +454,26 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
     o.row[0] = a.Uin; o.row[1] = a.Vin; o.row[2] = (DIAG == 2) ? a.W : a.IxF; o.row[3] = a.Dy; o.row[4] = a.D2y; o.row[5] = a.T2T;
   }
 
-  LDC_STAMP(0);
   // this wave's K groups: kq, kq+4, ... (ng of them); group n is 16-k block gk(n)
   const int ng = (T - kq + 3) / 4;
   auto gk = [&](int n) { return kq + 4 * n; };
   double* erow = lds + L::EROW + wv * kEdgeRowDoubles;
 
-  // ---- tiles with an index-(M-1) job: this wave's pieces of the six rows, LDS-direct, issued first
+  // ---- first fragments in flight before anything else ------------------------------------
+  RoleFrags fa, fb;
+  ExtraFrags fx;
+  load_role(fa, o, NB, I, J, ng > 0 ? gk(0) : 0, lane);
+
+  // The latch, the step counter and dt are only READ here (scalar loads, nobody waits for them yet); the
+  // latch is acted upon after the K loop.  An early `return` at this point made the compiler sink the
+  // fragment loads below it: kernel arguments -> latch -> operand pointers -> fragments became four cold
+  // misses in a row (~1.4 us before the first MFMA).  A latched launch now runs its K loop for nothing,
+  // which only happens in the last partial batch of a solve.
+  const int latched = DUMP ? 0 : sload(a.ctrl + LDC_CTRL_DONE);
+  const int step0 = sload(a.ctrl + LDC_CTRL_STEP);
+  const double adt = a.alpha * sload(a.scal + LDC_SCAL_DT);
+
+  // ---- tiles with an index-(M-1) job: this wave's pieces of the six rows, LDS-direct
   if (anyE) {
     const int h = lane & 1, q = (lane >> 1) & 3, gi = (lane >> 3) & 3, sl = lane >> 5;
     const size_t off = (size_t)m1 * LD + 16 * (kq + 4 * gi) + 4 * q + 2 * h;
@@ -469,16 +486,6 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
     if (live && (sl ? needB : needA) && s23 != nullptr) dma16(s23 + off, erow + 128);
     if (live && needB && s45 != nullptr) dma16(s45 + off, erow + 256);
   }
-
-  // ---- first fragments in flight before anything else ------------------------------------
-  RoleFrags fa, fb;
-  ExtraFrags fx;
-  load_role(fa, o, NB, I, J, ng > 0 ? gk(0) : 0, lane);
-
-  // the latch and dt are read only now, behind the first operand loads (reads are harmless)
-  if (!DUMP && sload(a.ctrl + LDC_CTRL_DONE) != 0) return;
-  const int step0 = sload(a.ctrl + LDC_CTRL_STEP);
-  const double adt = a.alpha * sload(a.scal + LDC_SCAL_DT);
 
   // ---- pointwise operands of the epilogue, issued now so that they land under the MFMAs ----------
   // threads 0..255 own node (i, j) of the tile; in a tile with an index-(M-1) job threads 256.. own
@@ -543,6 +550,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   }
 
   LDC_STAMP(2);
+  if (latched != 0) return;     // block-uniform; nothing has been stored yet
   // ---- all partial results to LDS ---------------------------------------------------------------
 #pragma unroll
   for (int q = 0; q < NA; ++q)
