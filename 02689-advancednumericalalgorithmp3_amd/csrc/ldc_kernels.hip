@@ -52,21 +52,14 @@ __device__ __forceinline__ v4d ldpk(const double* XK, int NB, int R, int G, int 
   return *reinterpret_cast<const v4d*>(XK + (((size_t)(R * NB + G) << 6) + lane) * 4);
 }
 
-// Store of state that only LATER launches read: agent-scope write-through (global_store ... sc1).  The bytes
-// leave the XCD's L2 while the other tiles still compute instead of at the end-of-kernel write-back
-// (4-7 MB dirty per stage launch): -2.1 us per iteration at N=256; non-temporal stores bought nothing.
-// (LDC_STORE_MODE 0 = plain, 2 = non-temporal: kept for A/B timing with tools/ab_iter.py)
-#ifndef LDC_STORE_MODE
-#define LDC_STORE_MODE 1
-#endif
-__device__ __forceinline__ void st_out(double* p, double v) {
-#if LDC_STORE_MODE == 1
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#elif LDC_STORE_MODE == 2
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
+// Store of state that only LATER launches read.  wt != 0: agent-scope write-through (global_store ... sc1): the
+// bytes leave the XCD's L2 while the other tiles still compute instead of at the end-of-kernel write-back
+// (N=256: 4-7 MB dirty per stage launch, -3.3 us per iteration; neutral at N <= 64; non-temporal stores bought
+// nothing).  The kernels must hold their argument block BY VALUE for this: through a reference into device memory
+// (batched launches) every such store made the compiler re-load the fields it needed next.
+__device__ __forceinline__ void st_out(double* p, double v, int wt) {
+  if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
 }
 
 // wave-uniform value that no thread of THIS launch writes: scalar load (waits on lgkmcnt, not on the
@@ -201,6 +194,7 @@ struct StageArgs {
   const double *DxK, *D2xK, *DyK, *D2yK, *IxFK, *GxFK;
   const double *UinK, *UinTK, *VinK, *VinTK, *T1TK, *T2TK;
   double *UoutK, *UoutTK, *VoutK, *VoutTK, *PoutK, *WK, *WTK;
+  int wt;   // write-through stores (st_out)
 };
 
 // slots of the stage-4 partial sums
@@ -208,6 +202,9 @@ enum { PS_DU2 = 0, PS_DV2, PS_U02, PS_V02, PS_RU2, PS_RV2, PS_RP2, PS_E, PS_NSUM
 static_assert(PS_N <= LDC_NPART, "partials row too small");
 static_assert(PS_NSUM == 8, "stage-4 reduction assigns one wave per sum");
 
+#ifndef LDC_WT_MIN_TILES
+#define LDC_WT_MIN_TILES 1       // see st_out: write-through measured neutral-or-better at every size (tools/ab_*.py)
+#endif
 constexpr int kStageWaves = 8;                 // 2 waves per SIMD: needed to saturate the f64 MFMA pipe
 constexpr int kStageThreads = 64 * kStageWaves;
 // timing experiments (ldc_debug_stamps): cycle stamps per wave at fixed points of the stage kernel
@@ -413,7 +410,9 @@ struct StageLds {
 //        of iteration n and are folded by the finalize block of the next post launch.
 template <bool GPV, bool LAST, bool DUMP, bool BATCH, int DIAG>
 __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs a_val, const StageArgs* a_arr) {
-  const StageArgs& a = BATCH ? a_arr[blockIdx.y] : a_val;
+  // by value: with a reference into device memory (BATCH) every write-through store made the compiler re-load the
+  // fields it needs next (+3 us per launch)
+  const StageArgs a = BATCH ? a_arr[blockIdx.y] : a_val;
   constexpr bool GP = GPV || (DIAG == 2);      // "has a fifth contraction" (grad p or grad omega)
   static_assert(!(GPV && DIAG == 2), "stage 2 of SG carries no pressure contraction");
   constexpr int VEL = (LAST || DUMP) ? 1 : (DIAG == 1 ? 2 : 0);   // what the nodes of index M-1 need here
@@ -622,14 +621,14 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
       px = valid ? C(0, 4) : 0.0;   // row M-1 of T1T/T2T meets a zero column of GxF/IxF: no completion term
       py = valid ? C(1, 4) : 0.0;
       if (!DUMP) {
-        st_out(a.PX + ij, px); st_out(a.PY + ij, py);
-        if (colnode) { st_out(a.PX + (size_t)M * LD + i, px); st_out(a.PY + (size_t)M * LD + i, py); }
+        st_out(a.PX + ij, px, a.wt); st_out(a.PY + ij, py, a.wt);
+        if (colnode) { st_out(a.PX + (size_t)M * LD + i, px, a.wt); st_out(a.PY + (size_t)M * LD + i, py, a.wt); }
       }
     }
     if (DIAG == 1) {
       const double w = valid ? (vx - uy) : 0.0;          // sg.py:510-522 on phi^(n+1) (= this stage's input)
-      st_out(a.W + ij, w);
-      if (owner) tw[ti * 17 + tj] = w; else st_out(a.WT + (size_t)j * LD + i, w);
+      st_out(a.W + ij, w, a.wt);
+      if (owner) tw[ti * 17 + tj] = w; else st_out(a.WT + (size_t)j * LD + i, w, a.wt);
       dsum = valid ? wq * w * w : 0.0;
     }
     if (DIAG == 2) {
@@ -653,11 +652,11 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
       if (!valid) { un = 0.0; vn = 0.0; }
       else if (j == M - 1) { un = lidv; vn = 0.0; }
       else if (i == 0 || i == M - 1 || j == 0) { un = 0.0; vn = 0.0; }
-      st_out(a.Uout + ij, un);
-      st_out(a.Vout + ij, vn);
+      st_out(a.Uout + ij, un, a.wt);
+      st_out(a.Vout + ij, vn, a.wt);
       if (a.Pout != nullptr && !(a.ablate & 32)) {
         const double pn = interior ? (p0 + adt * Rp) : 0.0;
-        st_out(a.Pout + ij, pn);
+        st_out(a.Pout + ij, pn, a.wt);
         tp[ti * 17 + tj] = pn;
       }
       tu[ti * 17 + tj] = un;
@@ -691,18 +690,18 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   if (owner && !(a.ablate & 8)) {
     const int tr = tid >> 4, tc = tid & 15;   // write UT[c0+tr][r0+tc] = tile[tc][tr]
     const size_t ot = (size_t)(c0 + tr) * LD + r0 + tc;
-    st_out(a.UoutT + ot, tu[tc * 17 + tr]);
-    st_out(a.VoutT + ot, tv[tc * 17 + tr]);
-    if (DIAG == 1) st_out(a.WT + ot, tw[tc * 17 + tr]);
+    st_out(a.UoutT + ot, tu[tc * 17 + tr], a.wt);
+    st_out(a.VoutT + ot, tv[tc * 17 + tr], a.wt);
+    if (DIAG == 1) st_out(a.WT + ot, tw[tc * 17 + tr], a.wt);
     // packed twins of this tile: block (I, J) of the array, block (J, I) of its transposed copy; thread t
     // stores double t of the 2-KB block = element (row pr, column pc) of the block
     const int pl = tid >> 2, pr = pl & 15, pc = 4 * (pl >> 4) + (tid & 3);
     const size_t kb = ((size_t)(I * NB + J) << 8) + tid, kbT = ((size_t)(J * NB + I) << 8) + tid;
     const int e = pr * 17 + pc, eT = pc * 17 + pr;
-    st_out(a.UoutK + kb, tu[e]); st_out(a.UoutTK + kbT, tu[eT]);
-    st_out(a.VoutK + kb, tv[e]); st_out(a.VoutTK + kbT, tv[eT]);
-    if (DIAG == 1) { st_out(a.WK + kb, tw[e]); st_out(a.WTK + kbT, tw[eT]); }
-    if (a.Pout != nullptr && !(a.ablate & 32)) st_out(a.PoutK + kb, tp[e]);
+    st_out(a.UoutK + kb, tu[e], a.wt); st_out(a.UoutTK + kbT, tu[eT], a.wt);
+    st_out(a.VoutK + kb, tv[e], a.wt); st_out(a.VoutTK + kbT, tv[eT], a.wt);
+    if (DIAG == 1) { st_out(a.WK + kb, tw[e], a.wt); st_out(a.WTK + kbT, tw[eT], a.wt); }
+    if (a.Pout != nullptr && !(a.ablate & 32)) st_out(a.PoutK + kb, tp[e], a.wt);
   }
   if (DIAG != 0) {
     // one partial sum per work-group into the parity slab of the state this stage started from
@@ -880,7 +879,7 @@ struct PostArgs {
   long long stride;
   int ungated;     // stand-alone calls: always run
   int fin_block;   // index of the finalize block in this launch, or -1
-  int NB;
+  int NB, wt;
   const double *PK, *IyFK, *GyFK;   // packed twins read by the T tiles
   double *T1TK, *T2TK;              // packed twins they keep in step
   FinalArgs fin;
@@ -888,7 +887,7 @@ struct PostArgs {
 
 template <bool BATCH>
 __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, const PostArgs* a_arr) {
-  const PostArgs& a = BATCH ? a_arr[blockIdx.y] : a_val;
+  const PostArgs a = BATCH ? a_arr[blockIdx.y] : a_val;   // by value, see stage_kernel
   __shared__ __attribute__((aligned(16))) double red[kThreads * (PS_N + 2)];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int M = a.M, LD = a.LD, T = a.T, nt = T * T, m1 = M - 1;
@@ -938,14 +937,14 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
     const int tr = tid >> 4, tc = tid & 15;
     const size_t o = (size_t)(c0 + tr) * LD + r0 + tc;
     const bool ok = (c0 + tr < M) && (r0 + tc < M);
-    st_out(a.T1T + o, ok ? t1[tc * 17 + tr] : 0.0);
-    st_out(a.T2T + o, ok ? t2[tc * 17 + tr] : 0.0);
+    st_out(a.T1T + o, ok ? t1[tc * 17 + tr] : 0.0, a.wt);
+    st_out(a.T2T + o, ok ? t2[tc * 17 + tr] : 0.0, a.wt);
     {   // packed twins: block (J, I) of T1T / T2T, thread t stores double t (row pr, column pc of the block)
       const int pl = tid >> 2, pr = pl & 15, pc = 4 * (pl >> 4) + (tid & 3);
       const size_t kbT = ((size_t)(J * a.NB + I) << 8) + tid;
       const bool okp = (c0 + pr < M) && (r0 + pc < M);
-      st_out(a.T1TK + kbT, okp ? t1[pc * 17 + pr] : 0.0);
-      st_out(a.T2TK + kbT, okp ? t2[pc * 17 + pr] : 0.0);
+      st_out(a.T1TK + kbT, okp ? t1[pc * 17 + pr] : 0.0, a.wt);
+      st_out(a.T2TK + kbT, okp ? t2[pc * 17 + pr] : 0.0, a.wt);
     }
     return;
   }
@@ -958,7 +957,7 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
       const double* pk = a.P + (size_t)k * LD;
       const double t1 = dot_rows(pk, a.IyF + (size_t)m1 * LD, M, lane);
       const double t2 = dot_rows(pk, a.GyF + (size_t)m1 * LD, M, lane);
-      if (lane == 0) { st_out(a.T1T + (size_t)m1 * LD + k, t1); st_out(a.T2T + (size_t)m1 * LD + k, t2); }
+      if (lane == 0) { st_out(a.T1T + (size_t)m1 * LD + k, t1, a.wt); st_out(a.T2T + (size_t)m1 * LD + k, t2, a.wt); }
     }
     return;
   }
@@ -1320,6 +1319,14 @@ namespace {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// write-through stores (st_out); ldc_debug_ablate bits 128 / 256 force plain / write-through for A/B timing
+// (tiles = work-groups of 16 x 16 nodes in the launch, all trials of a batch together)
+int write_through_policy(const ldc_solver* s, int tiles) {
+  if (s->ablate & 128) return 0;
+  if (s->ablate & 256) return 1;
+  return tiles >= LDC_WT_MIN_TILES ? 1 : 0;
+}
+
 StageArgs make_stage_args(const ldc_solver* s, int k) {
   const ldc_problem& p = s->p;
   StageArgs a;
@@ -1339,6 +1346,7 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
   a.partZ0 = p.partials + p.partials_stride; a.partP0 = p.partials + 3 * p.partials_stride;
   a.stride = p.partials_stride;
   a.ablate = s->stamps ? s->ablate : (s->ablate & ~64);
+  a.wt = write_through_policy(s, s->nt);
   a.dump[0] = s->stamps;
   // ping-pong: 0: S0 -> A, 1: A -> B, 2: B -> A, 3: A -> S0 (in place)
   const double *in[4][4] = {{p.U, p.UT, p.V, p.VT}, {p.UA, p.UAT, p.VA, p.VAT},
@@ -1431,6 +1439,7 @@ PostArgs make_post_args(const ldc_solver* s, const double* P, int do_omega, int 
   a.Dx = p.Dx; a.Dy = p.Dy; a.IyF = p.IyF; a.GyF = p.GyF;
   a.U = p.U; a.V = p.V; a.VT = p.VT; a.P = P;
   a.NB = p.LD / 16;
+  a.wt = write_through_policy(s, s->nt);
   a.PK = (P == p.PA) ? p.PAK : (P == p.PB) ? p.PBK : p.PK;
   a.IyFK = p.IyFK; a.GyFK = p.GyFK; a.T1TK = p.T1TK; a.T2TK = p.T2TK;
   a.T1T = p.T1T; a.T2T = p.T2T; a.W = p.W; a.WT = p.WT; a.wx = p.wx; a.wy = p.wy;
@@ -1766,20 +1775,28 @@ int ldc_batch_create(ldc_solver* const* solvers, int n_trials, void* workspace, 
   };
   for (int k = 0; k < 4; ++k) {
     std::vector<StageArgs> h(n_trials);
-    for (int q = 0; q < n_trials; ++q) h[q] = make_stage_args(solvers[q], k);
+    for (int q = 0; q < n_trials; ++q) {
+      h[q] = make_stage_args(solvers[q], k);
+      h[q].wt = write_through_policy(solvers[q], solvers[q]->nt * n_trials);
+    }
     b->d_stage[k] = reinterpret_cast<StageArgs*>(carve(sizeof(StageArgs) * n_trials));
     put(b->d_stage[k], h.data(), sizeof(StageArgs) * n_trials);
   }
   for (int wd = 0; wd < 2; ++wd) {
     std::vector<PostArgs> h(n_trials);
-    for (int q = 0; q < n_trials; ++q) h[q] = make_post_args(solvers[q], solvers[q]->p.P, 0, 1, wd, &b->post_grid[wd]);
+    for (int q = 0; q < n_trials; ++q) {
+      h[q] = make_post_args(solvers[q], solvers[q]->p.P, 0, 1, wd, &b->post_grid[wd]);
+      h[q].wt = write_through_policy(solvers[q], solvers[q]->nt * n_trials);
+    }
     b->d_post[wd] = reinterpret_cast<PostArgs*>(carve(sizeof(PostArgs) * n_trials));
     put(b->d_post[wd], h.data(), sizeof(PostArgs) * n_trials);
   }
   for (int ab = 0; ab < 2; ++ab) {
     std::vector<PostArgs> h(n_trials);
-    for (int q = 0; q < n_trials; ++q)
+    for (int q = 0; q < n_trials; ++q) {
       h[q] = make_post_args(solvers[q], ab == 0 ? solvers[q]->p.PA : solvers[q]->p.PB, 0, 0, 0, &b->postT_grid);
+      h[q].wt = write_through_policy(solvers[q], solvers[q]->nt * n_trials);
+    }
     b->d_postT[ab] = reinterpret_cast<PostArgs*>(carve(sizeof(PostArgs) * n_trials));
     put(b->d_postT[ab], h.data(), sizeof(PostArgs) * n_trials);
   }

@@ -205,8 +205,9 @@ int ldc_poisson_fastdiag(const double *Qx, const double *Qxinv, const double *Qy
 int ldc_vortex_extrema(const double *Psi, const double *W, const double *x, const double *y,
                        int M, int LD, double *out_val, int32_t *out_idx, void *stream);
 
-/* timing experiments only (results are WRONG while set): bit 0 skips the MFMAs, bit 1 the   */
-/* operand loads of the stage kernel                                                       */
+/* timing experiments only (results are WRONG while bits 0-5 are set): bit 0 skips the MFMAs, bit 1 the   */
+/* operand loads of the stage kernel; bits 7 / 8 (128 / 256) force plain / write-through state stores       */
+/* (results stay right; takes effect for launches and graphs built afterwards)                              */
 int ldc_debug_ablate(ldc_solver *s, int mask);
 /* Timing experiments: with mask bit 64 set every wave of the stage kernel writes seven cycle stamps
  * (s_memtime) to buf[((block * 8 + wave) * 8 + point)]; buf holds T*T*64 doubles.  NULL switches off. */

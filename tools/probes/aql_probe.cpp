@@ -80,7 +80,9 @@ int main(int argc, char** argv) {
   CK(hsa_amd_memory_fill(buf, 0, nbuf * 2));   // count in uint32 words
   CK(hsa_amd_memory_fill(out, 0, nout * 2));
 
-  struct Args { const double* buf; double* out; int mode; int pad; };
+  struct Args { const double* buf; double* out; int mode; unsigned int target; unsigned int* counters; };
+  unsigned int* counters; CK(hsa_amd_memory_pool_allocate(g_dev_pool, 4096, 0, (void**)&counters));
+  CK(hsa_amd_memory_fill(counters, 0, 1024));
   const int NARG = 64;
   std::vector<int> slot_mode;   // kernarg slot -> mode word
   char* hk; CK(hsa_amd_memory_pool_allocate(g_karg_pool, 4096 * NARG, 0, (void**)&hk));
@@ -91,7 +93,7 @@ int main(int argc, char** argv) {
     memset(hk + 4096 * m, 0, 4096);
     const int md = m < int(sizeof modes / sizeof modes[0]) ? modes[m] : 2 | (3 << 4);
     slot_mode.push_back(md);
-    Args a{buf, out, md, 0}; memcpy(hk + 4096 * m, &a, sizeof a);
+    Args a{buf, out, md, 0, counters}; memcpy(hk + 4096 * m, &a, sizeof a);
   }
   auto slot_of = [&](int md) { for (int m = 0; m < NARG; ++m) if (slot_mode[m] == md) return m; fprintf(stderr, "no slot for mode %d\n", md); exit(2); return 0; };
   char* kargs = hk;
@@ -184,6 +186,65 @@ int main(int argc, char** argv) {
 
   const int AG = HSA_FENCE_SCOPE_AGENT, NO = HSA_FENCE_SCOPE_NONE;
   chain(2, AG, AG, 60000, "warm-up");
+  // ---- overlapped chain: per-dispatch kernarg slots (64 B apart) carrying the arrival target --------------------
+  const int OC = 3000;
+  char* ok_host; CK(hsa_amd_memory_pool_allocate(g_karg_pool, 64 * OC, 0, (void**)&ok_host));
+  CK(hsa_amd_agents_allow_access(1, &g_gpu, nullptr, ok_host));
+  char* ok_dev; CK(hsa_amd_memory_pool_allocate(g_dev_pool, 64 * OC, 0, (void**)&ok_dev));
+  unsigned int launches_so_far = 0;   // synced launches since the counters were zeroed
+  auto overlapped = [&](int mode, bool barrier, bool sync, uint32_t lds_bytes, const char* label) {
+    double best = 1e30, worst = 0;
+    for (int rep = 0; rep < 5; ++rep) {
+      for (int i = 0; i < OC; ++i) {
+        Args a{buf, out, mode | (sync ? (1 << 16) : 0), 256u * (launches_so_far + i), counters};
+        memset(ok_host + 64 * i, 0, 64); memcpy(ok_host + 64 * i, &a, sizeof a);
+      }
+      CK(hsa_memory_copy(ok_dev, ok_host, 64 * OC));
+      hsa_signal_store_relaxed(sig[0], 1); hsa_signal_store_relaxed(sig[1], 1);
+      const uint32_t mask = q->size - 1;
+      auto t0 = std::chrono::steady_clock::now();
+      uint64_t idx0 = hsa_queue_add_write_index_relaxed(q, OC);
+      for (int i = 0; i < OC; ++i) {
+        hsa_kernel_dispatch_packet_t* p = (hsa_kernel_dispatch_packet_t*)q->base_address + ((idx0 + i) & mask);
+        p->setup = 1; p->workgroup_size_x = 512; p->workgroup_size_y = 1; p->workgroup_size_z = 1;
+        p->grid_size_x = 256 * 512; p->grid_size_y = 1; p->grid_size_z = 1;
+        p->private_segment_size = k.priv; p->group_segment_size = k.group + lds_bytes;
+        p->kernel_object = k.object; p->kernarg_address = ok_dev + 64 * i; p->reserved2 = 0;
+        const bool first = (i == 0), last = (i == OC - 1);
+        p->completion_signal = last ? sig[1] : hsa_signal_t{0};
+        uint16_t hdr = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) |
+                       (((barrier || first || last) ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
+                       (((first || last) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                       (((first || last) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT) << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+        __atomic_store_n((uint16_t*)p, hdr, __ATOMIC_RELEASE);
+      }
+      hsa_signal_store_screlease(q->doorbell_signal, idx0 + OC - 1);
+      while (hsa_signal_wait_scacquire(sig[1], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) != 0) {}
+      double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / OC;
+      if (sync) launches_so_far += OC;
+      if (us < best) best = us; if (us > worst) worst = us;
+    }
+    double flag = 0; CK(hsa_memory_copy(&flag, out, 8));
+    printf("%-84s min %.2f max %.2f us/dispatch%s\n", label, best, worst, flag < 0 ? "  [SPIN TIMEOUT]" : "");
+  };
+  if (getenv("AQL_PROBE_OVERLAP")) {
+    chain(2, AG, AG, 60000, "warm-up");
+    const int PK = 2 | (3 << 12) | (1 << 14);   // packed blocks, one group ahead
+    const int EMPTY = 2 | (3 << 4);
+    for (uint32_t lds : {0u, 100u * 1024u}) {
+      char lab[160];
+      snprintf(lab, sizeof lab, "LDS %3u KB: empty kernel, barrier bit", lds >> 10); overlapped(EMPTY, true, false, lds, lab);
+      snprintf(lab, sizeof lab, "LDS %3u KB: empty kernel, no barrier bit, no sync", lds >> 10); overlapped(EMPTY, false, false, lds, lab);
+      snprintf(lab, sizeof lab, "LDS %3u KB: empty kernel, no barrier bit, counter sync", lds >> 10); overlapped(EMPTY, false, true, lds, lab);
+      snprintf(lab, sizeof lab, "LDS %3u KB: packed operand reads, barrier bit", lds >> 10); overlapped(PK, true, false, lds, lab);
+      snprintf(lab, sizeof lab, "LDS %3u KB: packed operand reads, barrier bit + counter sync", lds >> 10); overlapped(PK, true, true, lds, lab);
+      snprintf(lab, sizeof lab, "LDS %3u KB: packed operand reads, no barrier bit, no sync", lds >> 10); overlapped(PK, false, false, lds, lab);
+      snprintf(lab, sizeof lab, "LDS %3u KB: packed operand reads, no barrier bit, counter sync", lds >> 10); overlapped(PK, false, true, lds, lab);
+    }
+    printf("done\n");
+    return 0;
+  }
+
   auto best_of = [&](int mode, int acq, int rel, const char* lab) {
     double best = 1e30, worst = 0;
     for (int rep = 0; rep < 5; ++rep) {

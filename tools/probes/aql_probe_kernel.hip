@@ -82,7 +82,33 @@ __device__ __forceinline__ double sum_fragments(const double* const pan[4], int 
 //       work-group the same 8 panels, 2: private panels per work-group),
 //       bits 12-13 shape (0: contiguous panel per wave, 1-3: fragment shape with DEPTH 0-2; tile pattern only)
 //       bits 14-15 packing of the fragment shapes (0 row-major, 1 packed blocks 32-byte stride, 2 packed slabs)
-extern "C" __global__ __launch_bounds__(512) void read_panels(const double* buf, double* out, int mode) {
+// Overlapped chain (mode bit 16): the launch carries no barrier bit; a work-group first waits until every
+// work-group of the previous launch has arrived (8 per-XCD counters, 128 B apart, target = 256 x launches so far),
+// and arrives itself at the end.  Spins are bounded: on a timeout the work-group flags out[0] and carries on.
+__device__ __forceinline__ void chain_wait(unsigned int* counters, unsigned int target, double* out) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    for (int spin = 0; spin < (1 << 18); ++spin) {
+      unsigned int v = lane < 8 ? __hip_atomic_load(counters + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+      if (__shfl(v, 0) >= target) break;
+      if (spin == (1 << 18) - 1 && lane == 0) out[0] = -1.0;
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void chain_arrive(unsigned int* counters) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7;   // HW_REG_XCC_ID, 4 bits
+    __hip_atomic_fetch_add(counters + xcc * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+extern "C" __global__ __launch_bounds__(512) void read_panels(const double* buf, double* out, int mode, unsigned int target,
+                                                              unsigned int* counters) {
+  if (mode & (1 << 16)) chain_wait(counters, target, out);
   const int b = blockIdx.x, xcd = b & 7, w = b >> 3;
   const int I = (xcd >> 1) * 4 + (w & 3), J = (xcd & 1) * 8 + (w >> 2);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -121,4 +147,5 @@ extern "C" __global__ __launch_bounds__(512) void read_panels(const double* buf,
     if (lane == 0) out[4096 + b * 8 + wv] = s;   // one plain 8-byte store per wave
   }
   if (s == 123.456) out[b * 512 + threadIdx.x] = s;   // never true: keeps the loads alive
+  if (mode & (1 << 16)) chain_arrive(counters);
 }
