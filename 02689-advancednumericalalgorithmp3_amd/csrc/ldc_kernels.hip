@@ -149,20 +149,22 @@ __device__ __forceinline__ void block_reduce_store(double (&sums)[NV], double (&
   }
 }
 
-// blockIdx -> tile.  Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an
-// L2), so give each XCD a compact (T/2 x T/4 when T%8==0) patch of tiles: the operand
-// panels it re-reads then stay in its own L2.  Pure speed; any bijection is correct.
+// blockIdx -> tile.  Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so give each XCD a
+// compact (T/4 x T/2 when T%8==0) patch of tiles: the operand panels it re-reads then stay in its own L2.
+// Inside a patch the order is column-major with the columns rotated by the row, so that the diagonal tiles (I, I)
+// and the tiles (I, I+1 mod T) come FIRST: they carry the index-(M-1) jobs (stage kernel) and run 1-2 us longer,
+// and a launch dispatches its 256 work-groups over ~1.7 us in block order -- started first, their extra time
+// hides under the ramp instead of ending the launch late.  Pure speed; any bijection is correct.
 // Branch-free on purpose: a branch here splits the kernel's entry block, and the scalar loads of the
 // kernel arguments used after it are then issued one cold miss after the other instead of together.
 __device__ __forceinline__ void tile_of_block(int b, int T, int& I, int& J) {
   const bool patched = (T & 7) == 0;
-  const int xcd = b & 7, loc = b >> 3;          // loc in [0, T*T/8)
-  const int pr = T >> 2, pc = patched ? (T >> 1) : 1;   // patch rows/cols: 4 x 2 patches
+  const int xcd = patched ? (b & 7) : 0, loc = patched ? (b >> 3) : b;
+  const int pr = patched ? (T >> 2) : T, pc = patched ? (T >> 1) : T;   // patch rows / columns (4 x 2 patches)
   const int pI = xcd >> 1, pJ = xcd & 1;
-  const int Ip = pI * pr + loc / pc, Jp = pJ * pc + loc % pc;
-  const int Iq = b / T, Jq = b - Iq * T;
-  I = patched ? Ip : Iq;
-  J = patched ? Jp : Jq;
+  const int jj = loc / pr, i = loc - jj * pr;
+  I = pI * pr + i;
+  J = pJ * pc + (I + jj) % pc;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -220,10 +222,24 @@ __device__ __forceinline__ double dot4(const v4d& x, const v4d& y) {
   return (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]);
 }
 // sum over the four k-quads of a wave: lanes l, l^16, l^32, l^48 hold the same (row|col) index
+// gfx950 lane-swap instructions instead of shuffles: a __shfl_xor of a double is two ds_bpermute round trips, and the
+// 15 sums a job tile needs after its K loop cost it ~1.2 us; v_permlane16_swap / v_permlane32_swap exchange the odd
+// 16- / 32-lane rows of one register with the even rows of another on the VALU.  Same association as before,
+// (x0 + x1) + (x2 + x3) over the four rows, so the results are bit-identical.
+template <bool ROWS32>
+__device__ __forceinline__ double swap_add(double x) {
+  const long long b = __builtin_bit_cast(long long, x);
+  const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+  const auto rl = ROWS32 ? __builtin_amdgcn_permlane32_swap(lo, lo, false, false)
+                         : __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto rh = ROWS32 ? __builtin_amdgcn_permlane32_swap(hi, hi, false, false)
+                         : __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double even = __builtin_bit_cast(double, ((long long)rh[0] << 32) | (long long)rl[0]);
+  const double odd = __builtin_bit_cast(double, ((long long)rh[1] << 32) | (long long)rl[1]);
+  return even + odd;     // every lane: its row pair's even-row value + odd-row value
+}
 __device__ __forceinline__ double quad_sum(double x) {
-  x += __shfl_xor(x, 16);
-  x += __shfl_xor(x, 32);
-  return x;
+  return swap_add<true>(swap_add<false>(x));
 }
 
 // One wave's operands.  Both roles contract the full 2x2 combination {A0,A1} x {B0,B1}:
@@ -259,8 +275,11 @@ __device__ __forceinline__ void load_role(RoleFrags& f, const RoleOps& o, int NB
 __device__ __forceinline__ void load_extra(ExtraFrags& x, const RoleOps& o, int NB, int I, int J, int G, int lane) {
   const int keep = (o.ablate & 2) ? 0 : 1;
   I *= keep; J *= keep; G *= keep; lane *= keep;
-  if (o.x4 != 1) x.a2 = ldpk(o.A2, NB, I, G, lane);
-  if (o.x4 != 2) x.b2 = ldpk(o.B2, NB, J, G, lane);
+  // both, always: a load that only one role issues makes the number of loads in flight path-dependent, and the
+  // compiler then waits with vmcnt(0) before every group's MFMAs (prefetch included).  The operand a role does
+  // not use (x4 = 1: a2, x4 = 2: b2) points at a panel it reads anyway (A0 / B0): a cache hit.  (Timing-neutral.)
+  x.a2 = ldpk(o.A2, NB, I, G, lane);
+  x.b2 = ldpk(o.B2, NB, J, G, lane);
 }
 
 // LDS-direct 16-byte load: lane l's 16 bytes land at lds_dst + 16*l bytes (lds_dst wave-uniform);
@@ -446,10 +465,10 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   o.role = role;
   o.x4 = (DIAG == 2) ? (role == 0 ? 1 : 2) : 0;
   if (role == 0) {
-    o.A0 = a.DxK; o.A1 = a.D2xK; o.B0 = a.UinTK; o.B1 = a.VinTK; o.A2 = a.GxFK; o.B2 = (DIAG == 2) ? a.WTK : a.T1TK;
+    o.A0 = a.DxK; o.A1 = a.D2xK; o.B0 = a.UinTK; o.B1 = a.VinTK; o.A2 = (DIAG == 2) ? a.DxK : a.GxFK; o.B2 = (DIAG == 2) ? a.WTK : a.T1TK;
     o.row[0] = a.Dx; o.row[1] = a.D2x; o.row[2] = a.GxF; o.row[3] = a.UinT; o.row[4] = a.VinT; o.row[5] = (DIAG == 2) ? a.WT : a.T1T;
   } else {
-    o.A0 = a.UinK; o.A1 = a.VinK; o.B0 = a.DyK; o.B1 = a.D2yK; o.A2 = (DIAG == 2) ? a.WK : a.IxFK; o.B2 = a.T2TK;
+    o.A0 = a.UinK; o.A1 = a.VinK; o.B0 = a.DyK; o.B1 = a.D2yK; o.A2 = (DIAG == 2) ? a.WK : a.IxFK; o.B2 = (DIAG == 2) ? a.DyK : a.T2TK;
     o.row[0] = a.Uin; o.row[1] = a.Vin; o.row[2] = (DIAG == 2) ? a.W : a.IxF; o.row[3] = a.Dy; o.row[4] = a.D2y; o.row[5] = a.T2T;
   }
 
@@ -457,6 +476,23 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   const int ng = (T - kq + 3) / 4;
   auto gk = [&](int n) { return kq + 4 * n; };
   double* erow = lds + L::EROW + wv * kEdgeRowDoubles;
+
+  // ---- tiles with an index-(M-1) job: this wave's pieces of the six rows, LDS-direct, issued FIRST:
+  // they are then older than every fragment load, so waiting for a fragment never leaves one of them pending (issued
+  // between the first fragments and the pointwise loads they made the compiler wait with vmcnt(0) before the MFMAs of
+  // every group, prefetch included: the K loop lost its overlap)
+  if (anyE) {
+    const int h = lane & 1, q = (lane >> 1) & 3, gi = (lane >> 3) & 3, sl = lane >> 5;
+    const size_t off = (size_t)m1 * LD + 16 * (kq + 4 * gi) + 4 * q + 2 * h;
+    const bool live = (kq + 4 * gi) < T;
+    const bool needA = rowE || cornE, needB = colE || cornE;
+    const double* s01 = sl ? o.row[1] : o.row[0];
+    const double* s23 = sl ? o.row[3] : o.row[2];
+    const double* s45 = sl ? o.row[5] : o.row[4];
+    if (live && needA && s01 != nullptr) dma16(s01 + off, erow);
+    if (live && (sl ? needB : needA) && s23 != nullptr) dma16(s23 + off, erow + 128);
+    if (live && needB && s45 != nullptr) dma16(s45 + off, erow + 256);
+  }
 
   // ---- first fragments in flight before anything else ------------------------------------
   RoleFrags fa, fb;
@@ -472,20 +508,6 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   const int step0 = sload(a.ctrl + LDC_CTRL_STEP);
   const double adt = a.alpha * sload(a.scal + LDC_SCAL_DT);
 
-  // ---- tiles with an index-(M-1) job: this wave's pieces of the six rows, LDS-direct
-  if (anyE) {
-    const int h = lane & 1, q = (lane >> 1) & 3, gi = (lane >> 3) & 3, sl = lane >> 5;
-    const size_t off = (size_t)m1 * LD + 16 * (kq + 4 * gi) + 4 * q + 2 * h;
-    const bool live = (kq + 4 * gi) < T;
-    const bool needA = rowE || cornE, needB = colE || cornE;
-    const double* s01 = sl ? o.row[1] : o.row[0];
-    const double* s23 = sl ? o.row[3] : o.row[2];
-    const double* s45 = sl ? o.row[5] : o.row[4];
-    if (live && needA && s01 != nullptr) dma16(s01 + off, erow);
-    if (live && (sl ? needB : needA) && s23 != nullptr) dma16(s23 + off, erow + 128);
-    if (live && needB && s45 != nullptr) dma16(s45 + off, erow + 256);
-  }
-
   // ---- pointwise operands of the epilogue, issued now so that they land under the MFMAs ----------
   // threads 0..255 own node (i, j) of the tile; in a tile with an index-(M-1) job threads 256.. own
   // that job's nodes (kind 0: (M-1, c0+idx), 1: (r0+idx, M-1), 2: the corner)
@@ -497,7 +519,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   const int j = owner ? (c0 + tj) : ((ekind == 0) ? (c0 + eidx) : m1);
   const size_t ij = (size_t)i * LD + j;
   double uin = 0, vin = 0, u0 = 0, v0 = 0, p0 = 0, px = 0, py = 0;
-  double dxl = 0, d2xl = 0, dyl = 0, d2yl = 0, ue = 0, ve = 0, un_ = 0, vn_ = 0, lidv = 0, wq = 0, we = 0, wn = 0;
+  double dxl = 0, d2xl = 0, dyl = 0, d2yl = 0, ue = 0, ve = 0, un_ = 0, vn_ = 0, lidv = 0, wxi = 0, wyj = 0, we = 0, wn = 0;
   // column nodes (r0+idx, M-1) read the transposed copies: contiguous instead of one cache line per lane
   // (16 lanes x 10 operands x a cold line each held the whole wave back by ~2 us); their grad p sits in
   // the padding row M of PX / PY, put there by stage 1
@@ -522,10 +544,18 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
       if (DIAG == 2) { we = a.W[(size_t)m1 * LD + j]; wn = a.WT[(size_t)m1 * LD + i]; }
     }
     lidv = a.ulid[i];
-    if (LAST || DIAG != 0) wq = a.wx[i] * a.wy[j];
+    // (only loaded here: their product is formed in the epilogue -- arithmetic on a loaded value at this point
+    //  makes the wave wait for every load issued so far, first fragments included: +1.2 us before the K loop)
+    if (LAST || DIAG != 0) { wxi = a.wx[i]; wyj = a.wy[j]; }
   }
 
   LDC_STAMP(1);
+  // Everything issued so far (LDS-direct rows, first fragments, pointwise operands) is drained HERE, once: with
+  // LDS-direct loads possibly outstanding the compiler otherwise protects every later LDS read and, after the loop's
+  // joins, every group's MFMAs with vmcnt(0) -- which also waits for the prefetch just issued (all variants with
+  // index-(M-1) handling had that).  With the drain the loop waits with vmcnt(8..14) as intended.  Measured effect on
+  // the iteration: none (+-0.2 us) -- the partner wave of the SIMD was covering the exposed latency.
+  if (EDGES) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), lgkmcnt / expcnt untouched
   // ---- contraction over k: this wave's quarter, loads one group ahead (A/B ping-pong) --------
   v4d acc[NA];
 #pragma unroll
@@ -595,6 +625,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   double* tw = tv + 16 * 17;
   double* tp = tw + 16 * 17;
 
+  const double wq = wxi * wyj;
   if (owner || edge_thr) {
     // ---- one code path for tile nodes and for the nodes of index M-1 ------------------------------
     // role 0: c0 du/dx, c1 dv/dx, c2 d2u/dx2, c3 d2v/dx2, c4 dp/dx | d(omega)/dx
