@@ -835,6 +835,7 @@ __device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t) 
     }
   }
   if (flush) {
+    // (loading these rows speculatively, together with the control words above, was measured: +0.7 us per iteration)
     const int par = (iter - 1) & 1;
     const double* pz = a.partZ0 + (size_t)par * a.stride;
     const double* pp = a.partP0 + (size_t)par * a.stride;
@@ -924,6 +925,22 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
   const int M = a.M, LD = a.LD, T = a.T, nt = T * T, m1 = M - 1;
   int b = (int)blockIdx.x;
   if (b == a.fin_block) { fin_work(a.fin, red, tid); return; }
+  // T tiles: the operand fragments of this wave's first four k-groups go out BEFORE the gate below (harmless
+  // reads); behind it every thread used to sit through a cold miss for two control words and a barrier before its
+  // first load, and then through one exposed load latency per group (-0.6 us per iteration at N=64, neutral at 256).
+  constexpr int kPre = 4;
+  const bool t_tile = b < nt;
+  int I = 0, J = 0;
+  v4d fP[kPre], fI[kPre], fG[kPre];
+  if (t_tile) {
+    tile_of_block(b, T, I, J);
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+      const int g = wv + u * kWaves < T ? wv + u * kWaves : 0;     // clamped: harmless reload, not used
+      fP[u] = ldpk(a.PK, a.NB, I, g, lane);
+      fI[u] = ldpk(a.IyFK, a.NB, J, g, lane); fG[u] = ldpk(a.GyFK, a.NB, J, g, lane);
+    }
+  }
   // After the latch nothing changes any more: once the last record is flushed every tile of
   // this launch would reproduce bit-identical output, so the whole launch may be skipped.
   // (Blocks may disagree while the finalize block of this very launch flips FLUSHED; that
@@ -941,19 +958,27 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
   if (gate[1]) return;
   double* partZ = a.partZ0 + (size_t)((step > 0 ? step - 1 : 0) & 1) * a.stride;
 
-  if (b < nt) {
+  if (t_tile) {
     // ---- T1T[j][i] = sum_k P[i][k] IyF[j][k],  T2T[j][i] = sum_k P[i][k] GyF[j][k] -------
-    int I, J;
-    tile_of_block(b, T, I, J);
     const int r0 = 16 * I, c0 = 16 * J;
     v4d acc[2] = {(v4d){0, 0, 0, 0}, (v4d){0, 0, 0, 0}};
-    for (int g = wv; g < T; g += kWaves) {
-      const v4d fP = ldpk(a.PK, a.NB, I, g, lane);
-      const v4d fI = ldpk(a.IyFK, a.NB, J, g, lane), fG = ldpk(a.GyFK, a.NB, J, g, lane);
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+      if (wv + u * kWaves < T) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[0] = MFMA_F64(fP[u][s], fI[u][s], acc[0]);
+          acc[1] = MFMA_F64(fP[u][s], fG[u][s], acc[1]);
+        }
+      }
+    }
+    for (int g = wv + kPre * kWaves; g < T; g += kWaves) {     // T > 16 only
+      const v4d gP = ldpk(a.PK, a.NB, I, g, lane);
+      const v4d gI = ldpk(a.IyFK, a.NB, J, g, lane), gG = ldpk(a.GyFK, a.NB, J, g, lane);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        acc[0] = MFMA_F64(fP[s], fI[s], acc[0]);
-        acc[1] = MFMA_F64(fP[s], fG[s], acc[1]);
+        acc[0] = MFMA_F64(gP[s], gI[s], acc[0]);
+        acc[1] = MFMA_F64(gP[s], gG[s], acc[1]);
       }
     }
     double s[2];
