@@ -48,8 +48,17 @@ __device__ __forceinline__ v4d ldfrag(const double* X, int ld, int r0, int k0, i
 
 // The same fragment from a packed twin: block (R, G) = rows 16R.., k = 16G.. is 256 doubles in the order the
 // lanes consume them, lane l's four k-steps at 4 l (include/ldc_hip.h, Conventions).  NB = LD / 16.
+// (explicitly GLOBAL address space, here and in gl / st_out: the batched kernels take their pointers from an
+//  argument block in device memory, where the compiler cannot infer it and falls back to flat_load / flat_store,
+//  which also count against lgkmcnt and made it wait with vmcnt(0) lgkmcnt(0) before every group's MFMAs)
+#define LDC_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ v4d ldpk(const double* XK, int NB, int R, int G, int lane) {
-  return *reinterpret_cast<const v4d*>(XK + (((size_t)(R * NB + G) << 6) + lane) * 4);
+  return *(const LDC_GLOBAL v4d*)(XK + (((size_t)(R * NB + G) << 6) + lane) * 4);
+}
+// element i of a device array
+template <typename T>
+__device__ __forceinline__ T gl(const T* p, size_t i) {
+  return ((const LDC_GLOBAL T*)p)[i];
 }
 
 // Store of state that only LATER launches read.  wt != 0: agent-scope write-through (global_store ... sc1): the
@@ -58,8 +67,8 @@ __device__ __forceinline__ v4d ldpk(const double* XK, int NB, int R, int G, int 
 // nothing).  The kernels must hold their argument block BY VALUE for this: through a reference into device memory
 // (batched launches) every such store made the compiler re-load the fields it needed next.
 __device__ __forceinline__ void st_out(double* p, double v, int wt) {
-  if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
+  if (wt) __hip_atomic_store((LDC_GLOBAL double*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *(LDC_GLOBAL double*)p = v;
 }
 
 // wave-uniform value that no thread of THIS launch writes: scalar load (waits on lgkmcnt, not on the
@@ -526,27 +535,27 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   const bool colnode = !owner && ekind == 1;
   const size_t ijT = (size_t)j * LD + i;
   if (owner || edge_thr) {
-    uin = (colnode ? a.UinT : a.Uin)[colnode ? ijT : ij];
-    vin = (colnode ? a.VinT : a.Vin)[colnode ? ijT : ij];
+    uin = gl(colnode ? a.UinT : a.Uin, colnode ? ijT : ij);
+    vin = gl(colnode ? a.VinT : a.Vin, colnode ? ijT : ij);
     if (!DUMP) {
-      u0 = (colnode ? a.U0T : a.U0)[colnode ? ijT : ij];
-      v0 = (colnode ? a.V0T : a.V0)[colnode ? ijT : ij];
+      u0 = gl(colnode ? a.U0T : a.U0, colnode ? ijT : ij);
+      v0 = gl(colnode ? a.V0T : a.V0, colnode ? ijT : ij);
     }
-    if (owner && !DUMP && a.Pout != nullptr) p0 = a.P0[ij];
+    if (owner && !DUMP && a.Pout != nullptr) p0 = gl(a.P0, ij);
     if (!GPV && (owner || VEL == 1)) {
       const size_t ip = colnode ? (size_t)M * LD + i : ij;
-      px = a.PX[ip]; py = a.PY[ip];
+      px = gl(a.PX, ip); py = gl(a.PY, ip);
     }
     if (a.tail) {
-      dxl = a.DxL[i]; d2xl = a.D2xL[i]; dyl = a.DyL[j]; d2yl = a.D2yL[j];
-      ue = a.Uin[(size_t)m1 * LD + j]; ve = a.Vin[(size_t)m1 * LD + j];    // east-wall row
-      un_ = a.UinT[(size_t)m1 * LD + i]; vn_ = a.VinT[(size_t)m1 * LD + i];  // lid column, read along the transposed copy
-      if (DIAG == 2) { we = a.W[(size_t)m1 * LD + j]; wn = a.WT[(size_t)m1 * LD + i]; }
+      dxl = gl(a.DxL, i); d2xl = gl(a.D2xL, i); dyl = gl(a.DyL, j); d2yl = gl(a.D2yL, j);
+      ue = gl(a.Uin, (size_t)m1 * LD + j); ve = gl(a.Vin, (size_t)m1 * LD + j);    // east-wall row
+      un_ = gl(a.UinT, (size_t)m1 * LD + i); vn_ = gl(a.VinT, (size_t)m1 * LD + i);  // lid column, read along the transposed copy
+      if (DIAG == 2) { we = gl(a.W, (size_t)m1 * LD + j); wn = gl(a.WT, (size_t)m1 * LD + i); }
     }
-    lidv = a.ulid[i];
+    lidv = gl(a.ulid, i);
     // (only loaded here: their product is formed in the epilogue -- arithmetic on a loaded value at this point
     //  makes the wave wait for every load issued so far, first fragments included: +1.2 us before the K loop)
-    if (LAST || DIAG != 0) { wxi = a.wx[i]; wyj = a.wy[j]; }
+    if (LAST || DIAG != 0) { wxi = gl(a.wx, i); wyj = gl(a.wy, j); }
   }
 
   LDC_STAMP(1);
