@@ -16,9 +16,10 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE J
               stage launches of a step).  `achieved` = necessary flops per launch (SURVEY 8d:
               8 contractions x 2 M^3 = 16 M^3) over the mean launch time measured with HIP
               events around back-to-back launches on the launch stream; `peak` = 78.6 TFLOP/s
-              fp64 matrix (AMD datasheet); the fp64 MFMA issue rate measured in this run
-              (~48 TFLOP/s: one v_mfma_f64_16x16x4 per ~100 cycles per SIMD) is reported as
-              `peak_measured`.
+              fp64 matrix (AMD datasheet).  `peak_measured` is the SUSTAINED fp64 MFMA rate of a
+              micro-benchmark in this run (~48 TFLOP/s: one v_mfma_f64_16x16x4 per ~100 cycles per
+              SIMD over 32 000 back-to-back MFMAs per wave) -- a power/clock figure, not the issue
+              limit: the 4-us K loop of the stage kernel runs at ~65 TFLOP/s.
 * cpu_baseline : the NumPy oracle (a port of the reference, pinned to its golden vectors)
               timed on this host's cores for a bounded sample of the same workload.
 """
