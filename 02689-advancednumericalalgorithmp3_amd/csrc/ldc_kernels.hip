@@ -227,8 +227,14 @@ constexpr int kStageThreads = 64 * kStageWaves;
 constexpr int kEdgeRowDoubles = 6 * 4 * 16;    // per wave: 6 rows of index M-1 x 4 groups x 16 (tail needs T <= 16)
 constexpr size_t kLdsLimit = 160 * 1024;
 
-__device__ __forceinline__ double dot4(const v4d& x, const v4d& y) {
-  return (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]);
+// acc += x . y as four chained FMAs: the index-(M-1) jobs run on the same FP64 units as the MFMAs next to them
+// (fp64 vector rate == fp64 matrix rate on this chip), so their cost is their operation count -- 4 per dot product
+// instead of the 6 of (x0 y0 + x1 y1) + (x2 y2 + x3 y3) followed by an add
+__device__ __forceinline__ void fma4(double& acc, const v4d& x, const v4d& y) {
+  acc = fma(x[0], y[0], acc);
+  acc = fma(x[1], y[1], acc);
+  acc = fma(x[2], y[2], acc);
+  acc = fma(x[3], y[3], acc);
 }
 // sum over the four k-quads of a wave: lanes l, l^16, l^32, l^48 hold the same (row|col) index
 // gfx950 lane-swap instructions instead of shuffles: a __shfl_xor of a double is two ds_bpermute round trips, and the
@@ -362,27 +368,27 @@ __device__ __forceinline__ void edge_group(EdgeAcc& e, const RoleFrags& f, const
   }
   if (rowE) {
     if (VEL == 1) {
-      e.er[0] += dot4(ar0, f.b0); e.er[1] += dot4(ar0, f.b1);
-      e.er[2] += dot4(ar1, f.b0); e.er[3] += dot4(ar1, f.b1);
+      fma4(e.er[0], ar0, f.b0); fma4(e.er[1], ar0, f.b1);
+      fma4(e.er[2], ar1, f.b0); fma4(e.er[3], ar1, f.b1);
     }
-    if (VEL == 2) e.er[0] += dot4(ar0, o.role == 0 ? f.b1 : f.b0);
-    if (GP) e.er[4] += dot4(xr, (o.x4 == 2) ? f.b0 : x.b2);
+    if (VEL == 2) fma4(e.er[0], ar0, o.role == 0 ? f.b1 : f.b0);
+    if (GP) fma4(e.er[4], xr, (o.x4 == 2) ? f.b0 : x.b2);
   }
   if (colE) {
     if (VEL == 1) {
-      e.ec[0] += dot4(f.a0, bc0); e.ec[1] += dot4(f.a0, bc1);
-      e.ec[2] += dot4(f.a1, bc0); e.ec[3] += dot4(f.a1, bc1);
+      fma4(e.ec[0], f.a0, bc0); fma4(e.ec[1], f.a0, bc1);
+      fma4(e.ec[2], f.a1, bc0); fma4(e.ec[3], f.a1, bc1);
     }
-    if (VEL == 2) e.ec[0] += dot4(f.a0, o.role == 0 ? bc1 : bc0);
-    if (GP) e.ec[4] += dot4((o.x4 == 1) ? f.a0 : x.a2, yc);
+    if (VEL == 2) fma4(e.ec[0], f.a0, o.role == 0 ? bc1 : bc0);
+    if (GP) fma4(e.ec[4], (o.x4 == 1) ? f.a0 : x.a2, yc);
   }
   if (cornE) {
     if (VEL == 1) {
-      e.ek[0] += dot4(ar0, bc0); e.ek[1] += dot4(ar0, bc1);
-      e.ek[2] += dot4(ar1, bc0); e.ek[3] += dot4(ar1, bc1);
+      fma4(e.ek[0], ar0, bc0); fma4(e.ek[1], ar0, bc1);
+      fma4(e.ek[2], ar1, bc0); fma4(e.ek[3], ar1, bc1);
     }
-    if (VEL == 2) e.ek[0] += dot4(ar0, o.role == 0 ? bc1 : bc0);
-    if (GP) e.ek[4] += dot4(xr, yc);
+    if (VEL == 2) fma4(e.ek[0], ar0, o.role == 0 ? bc1 : bc0);
+    if (GP) fma4(e.ek[4], xr, yc);
   }
 }
 
@@ -467,7 +473,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   const bool rowE = etile && (I == J);
   const bool colE = etile && (J == (I + 1) % T);
   const bool cornE = etile && (T >= 3 ? (I == 0 && J == 2) : (I == 0 && J == 0));
-  const bool anyE = rowE || colE || cornE;     // block-uniform
+  const bool anyE = (rowE || colE || cornE) && !(a.ablate & 512);     // block-uniform (512: timing, no K-loop part)
 
   RoleOps o;
   o.ablate = a.ablate;
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   // they are then older than every fragment load, so waiting for a fragment never leaves one of them pending (issued
   // between the first fragments and the pointwise loads they made the compiler wait with vmcnt(0) before the MFMAs of
   // every group, prefetch included: the K loop lost its overlap)
-  if (anyE) {
+  if (anyE && !(a.ablate & 2048)) {      // (2048: timing, no LDS-direct rows)
     const int h = lane & 1, q = (lane >> 1) & 3, gi = (lane >> 3) & 3, sl = lane >> 5;
     const size_t off = (size_t)m1 * LD + 16 * (kq + 4 * gi) + 4 * q + 2 * h;
     const bool live = (kq + 4 * gi) < T;
@@ -523,7 +529,8 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   const int ti = 4 * (wv & 3) + (lane >> 4), tj = lane & 15;
   const bool owner = tid < 256;
   const int ekind = (tid - 256) >> 4, eidx = (tid - 256) & 15;
-  const bool edge_thr = !owner && ((ekind == 0 && rowE) || (ekind == 1 && colE) || (ekind == 2 && eidx == 0 && cornE));
+  const bool edge_thr = !owner && !(a.ablate & 1024) &&     // (1024: timing, no epilogue part)
+                        ((ekind == 0 && rowE) || (ekind == 1 && colE) || (ekind == 2 && eidx == 0 && cornE));
   const int i = owner ? (r0 + ti) : ((ekind == 1) ? (r0 + eidx) : m1);
   const int j = owner ? (c0 + tj) : ((ekind == 0) ? (c0 + eidx) : m1);
   const size_t ij = (size_t)i * LD + j;
@@ -578,12 +585,12 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
     if (GP) load_extra(fx, o, NB, I, J, gk(n), lane);          // first: loads return in issue order
     load_role(fb, o, NB, I, J, gk(n + 1 < ng ? n + 1 : n), lane);   // clamped: harmless reload
     mfma_role<GP, NA>(fa, fx, acc, a.ablate, o.x4);
-    if (anyE) edge_group<VEL, GP>(ea, fa, fx, o, erow, n, lane, rowE, colE, cornE);
+    if (anyE && !(a.ablate & 4096)) edge_group<VEL, GP>(ea, fa, fx, o, erow, n, lane, rowE, colE, cornE);
     if (n + 1 < ng) {
       if (GP) load_extra(fx, o, NB, I, J, gk(n + 1), lane);
       load_role(fa, o, NB, I, J, gk(n + 2 < ng ? n + 2 : n + 1), lane);
       mfma_role<GP, NA>(fb, fx, acc, a.ablate, o.x4);
-      if (anyE) edge_group<VEL, GP>(ea, fb, fx, o, erow, n + 1, lane, rowE, colE, cornE);
+      if (anyE && !(a.ablate & 4096)) edge_group<VEL, GP>(ea, fb, fx, o, erow, n + 1, lane, rowE, colE, cornE);
     }
   }
 
@@ -599,8 +606,10 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
       if ((q == 0 && VEL == 0) || (q >= 1 && q < 4 && VEL != 1) || (q == 4 && !GP)) continue;
-      const double x = quad_sum(ea.er[q]), y = quad_sum(ea.ec[q]), z = quad_sum(ea.ek[q]);
-      if (lane < 16) { er[q * 16 + lane] = x; er[(5 + q) * 16 + lane] = y; er[(10 + q) * 16 + lane] = z; }
+      // only the kinds this tile carries (block-uniform; a reader only looks at its own kind's slots)
+      if (rowE) { const double x = quad_sum(ea.er[q]); if (lane < 16) er[q * 16 + lane] = x; }
+      if (colE) { const double y = quad_sum(ea.ec[q]); if (lane < 16) er[(5 + q) * 16 + lane] = y; }
+      if (cornE) { const double z = quad_sum(ea.ek[q]); if (lane < 16) er[(10 + q) * 16 + lane] = z; }
     }
   }
   __syncthreads();

@@ -208,6 +208,8 @@ int ldc_vortex_extrema(const double *Psi, const double *W, const double *x, cons
 /* timing experiments only (results are WRONG while bits 0-5 are set): bit 0 skips the MFMAs, bit 1 the   */
 /* operand loads of the stage kernel; bits 7 / 8 (128 / 256) force plain / write-through state stores       */
 /* (results stay right; takes effect for launches and graphs built afterwards)                              */
+/* bits 4 / 9-12 (16 / 512, 1024, 2048, 4096) switch parts of the index-(M-1) jobs off: all / K-loop part /     */
+/* epilogue part / LDS-direct rows / per-group dot products (the recorded |R|, Z, P then miss those nodes)        */
 int ldc_debug_ablate(ldc_solver *s, int mask);
 /* Timing experiments: with mask bit 64 set every wave of the stage kernel writes seven cycle stamps
  * (s_memtime) to buf[((block * 8 + wave) * 8 + point)]; buf holds T*T*64 doubles.  NULL switches off. */
