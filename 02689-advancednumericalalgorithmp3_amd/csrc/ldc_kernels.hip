@@ -206,6 +206,8 @@ struct StageArgs {
   const double *UinK, *UinTK, *VinK, *VinTK, *T1TK, *T2TK;
   double *UoutK, *UoutTK, *VoutK, *VoutTK, *PoutK, *WK, *WTK;
   int wt;   // write-through stores (st_out)
+  int rm_out;   // also store the row-major forms of the velocity outputs (stage 4 only: nothing reads those of the
+                // stage buffers -- tile nodes take their stage input from the packed twin, index M-1 is never rewritten)
 };
 
 // slots of the stage-4 partial sums
@@ -542,8 +544,14 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   const bool colnode = !owner && ekind == 1;
   const size_t ijT = (size_t)j * LD + i;
   if (owner || edge_thr) {
-    uin = gl(colnode ? a.UinT : a.Uin, colnode ? ijT : ij);
-    vin = gl(colnode ? a.VinT : a.Vin, colnode ? ijT : ij);
+    if (owner) {     // stage input at a tile node: from the packed twin (block (I, J), element (ti, tj))
+      const size_t kin = ((size_t)(I * NB + J) << 8) + (size_t)((((tj >> 2) << 4) + ti) << 2) + (tj & 3);
+      uin = gl(a.UinK, kin);
+      vin = gl(a.VinK, kin);
+    } else {         // node of index M-1: row-major forms (never rewritten by the tiles)
+      uin = gl(colnode ? a.UinT : a.Uin, colnode ? ijT : ij);
+      vin = gl(colnode ? a.VinT : a.Vin, colnode ? ijT : ij);
+    }
     if (!DUMP) {
       u0 = gl(colnode ? a.U0T : a.U0, colnode ? ijT : ij);
       v0 = gl(colnode ? a.V0T : a.V0, colnode ? ijT : ij);
@@ -701,8 +709,10 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
       if (!valid) { un = 0.0; vn = 0.0; }
       else if (j == M - 1) { un = lidv; vn = 0.0; }
       else if (i == 0 || i == M - 1 || j == 0) { un = 0.0; vn = 0.0; }
-      st_out(a.Uout + ij, un, a.wt);
-      st_out(a.Vout + ij, vn, a.wt);
+      if (a.rm_out) {
+        st_out(a.Uout + ij, un, a.wt);
+        st_out(a.Vout + ij, vn, a.wt);
+      }
       if (a.Pout != nullptr && !(a.ablate & 32)) {
         const double pn = interior ? (p0 + adt * Rp) : 0.0;
         st_out(a.Pout + ij, pn, a.wt);
@@ -739,8 +749,10 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   if (owner && !(a.ablate & 8)) {
     const int tr = tid >> 4, tc = tid & 15;   // write UT[c0+tr][r0+tc] = tile[tc][tr]
     const size_t ot = (size_t)(c0 + tr) * LD + r0 + tc;
-    st_out(a.UoutT + ot, tu[tc * 17 + tr], a.wt);
-    st_out(a.VoutT + ot, tv[tc * 17 + tr], a.wt);
+    if (a.rm_out) {
+      st_out(a.UoutT + ot, tu[tc * 17 + tr], a.wt);
+      st_out(a.VoutT + ot, tv[tc * 17 + tr], a.wt);
+    }
     if (DIAG == 1) st_out(a.WT + ot, tw[tc * 17 + tr], a.wt);
     // packed twins of this tile: block (I, J) of the array, block (J, I) of its transposed copy; thread t
     // stores double t of the 2-KB block = element (row pr, column pc) of the block
@@ -1421,6 +1433,7 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
   a.stride = p.partials_stride;
   a.ablate = s->stamps ? s->ablate : (s->ablate & ~64);
   a.wt = write_through_policy(s, s->nt);
+  a.rm_out = (k == 3) ? 1 : 0;
   a.dump[0] = s->stamps;
   // ping-pong: 0: S0 -> A, 1: A -> B, 2: B -> A, 3: A -> S0 (in place)
   const double *in[4][4] = {{p.U, p.UT, p.V, p.VT}, {p.UA, p.UAT, p.VA, p.VAT},

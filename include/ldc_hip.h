@@ -105,7 +105,9 @@ typedef struct ldc_problem {
   const double *DxL, *D2xL, *DyL, *D2yL; /* column M-1 of Dx, D2x, Dy, D2y as contiguous length-LD vectors */
   /* state phi^n and its transposed copies                                              */
   double *U, *UT, *V, *VT, *P;
-  /* RK stage buffers (sg.py:438-442), ping-pong A/B                                    */
+  /* RK stage buffers (sg.py:438-442), ping-pong A/B.  Of the velocity buffers the kernels maintain only the
+     packed twins (UAK ...); the row-major forms below are read at index M-1 only (boundary values, written by
+     the host) and are otherwise stale.  PA / PB are maintained in both forms.            */
   double *UA, *UAT, *VA, *VAT, *PA;
   double *UB, *UBT, *VB, *VBT, *PB;
   /* pressure path: T1T = (P IyF^T)^T, T2T = (P GyF^T)^T, grad p on the full grid       */
