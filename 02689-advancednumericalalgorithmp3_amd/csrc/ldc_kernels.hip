@@ -66,6 +66,14 @@ __device__ __forceinline__ T gl(const T* p, size_t i) {
 // (N=256: 4-7 MB dirty per stage launch, -3.3 us per iteration; neutral at N <= 64; non-temporal stores bought
 // nothing).  The kernels must hold their argument block BY VALUE for this: through a reference into device memory
 // (batched launches) every such store made the compiler re-load the fields it needed next.
+// 16-byte form (p 16-byte aligned).  There is no 16-byte atomic store to lower from; an asm store is safe here (no
+// result register, nothing in the kernel reads these bytes back, s_endpgm completes outstanding stores).
+__device__ __forceinline__ void st_out2(double* p, double v0, double v1, int wt) {
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  const v2d_t v = {v0, v1};
+  if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"((LDC_GLOBAL v2d_t*)p), "v"(v) : "memory");
+  else *(LDC_GLOBAL v2d_t*)p = v;
+}
 __device__ __forceinline__ void st_out(double* p, double v, int wt) {
   if (wt) __hip_atomic_store((LDC_GLOBAL double*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *(LDC_GLOBAL double*)p = v;
@@ -754,15 +762,19 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
       st_out(a.VoutT + ot, tv[tc * 17 + tr], a.wt);
     }
     if (DIAG == 1) st_out(a.WT + ot, tw[tc * 17 + tr], a.wt);
-    // packed twins of this tile: block (I, J) of the array, block (J, I) of its transposed copy; thread t
-    // stores double t of the 2-KB block = element (row pr, column pc) of the block
-    const int pl = tid >> 2, pr = pl & 15, pc = 4 * (pl >> 4) + (tid & 3);
-    const size_t kb = ((size_t)(I * NB + J) << 8) + tid, kbT = ((size_t)(J * NB + I) << 8) + tid;
+    // packed twins of this tile: block (I, J) of the array, block (J, I) of its transposed copy, 16 bytes per
+    // store: thread h = tid & 127 stores doubles 2h, 2h+1 of a 2-KB block = elements (row pr, columns pc, pc+1);
+    // threads 0..127 take the u (and omega) arrays, threads 128..255 the v (and p) arrays
+    const int hh = tid & 127, pl = hh >> 1, pr = pl & 15, pc = 4 * (pl >> 4) + 2 * (hh & 1);
+    const size_t kb = ((size_t)(I * NB + J) << 8) + 2 * hh, kbT = ((size_t)(J * NB + I) << 8) + 2 * hh;
     const int e = pr * 17 + pc, eT = pc * 17 + pr;
-    st_out(a.UoutK + kb, tu[e], a.wt); st_out(a.UoutTK + kbT, tu[eT], a.wt);
-    st_out(a.VoutK + kb, tv[e], a.wt); st_out(a.VoutTK + kbT, tv[eT], a.wt);
-    if (DIAG == 1) { st_out(a.WK + kb, tw[e], a.wt); st_out(a.WTK + kbT, tw[eT], a.wt); }
-    if (a.Pout != nullptr && !(a.ablate & 32)) st_out(a.PoutK + kb, tp[e], a.wt);
+    if (tid < 128) {
+      st_out2(a.UoutK + kb, tu[e], tu[e + 1], a.wt); st_out2(a.UoutTK + kbT, tu[eT], tu[eT + 17], a.wt);
+      if (DIAG == 1) { st_out2(a.WK + kb, tw[e], tw[e + 1], a.wt); st_out2(a.WTK + kbT, tw[eT], tw[eT + 17], a.wt); }
+    } else {
+      st_out2(a.VoutK + kb, tv[e], tv[e + 1], a.wt); st_out2(a.VoutTK + kbT, tv[eT], tv[eT + 17], a.wt);
+      if (a.Pout != nullptr && !(a.ablate & 32)) st_out2(a.PoutK + kb, tp[e], tp[e + 1], a.wt);
+    }
   }
   if (DIAG != 0) {
     // one partial sum per work-group into the parity slab of the state this stage started from
