@@ -893,16 +893,29 @@ __device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t) 
     if ((t & 63) == 0) sm[q * NW + (t >> 6)] = v[q];
   }
   __syncthreads();
-  if (t != 0) return;
-  double r[PS_N + 2];
-#pragma unroll
-  for (int q = 0; q < PS_N + 2; ++q) {
+  // Cross-wave totals, their square roots and the next dt by SEPARATE lanes, in parallel: this block is the critical
+  // path of the post launch and one lane doing eight fp64 square roots, the divisions and next_dt in a row is most of
+  // its tail.  Same operations on the same operands as the serial form: bit-identical.
+  __shared__ double fin_r[PS_N + 2], fin_sqrt[PS_N + 2], fin_dt;
+  auto total = [&](int q) {
     const bool is_max = (q == PS_UMAX || q == PS_VMAX);
     double x = sm[q * NW];
 #pragma unroll
     for (int w = 1; w < NW; ++w) x = is_max ? fmax(x, sm[q * NW + w]) : (x + sm[q * NW + w]);
-    r[q] = x;
+    return x;
+  };
+  if (t < PS_N + 2) {
+    const double x = total(t);
+    fin_r[t] = x;
+    fin_sqrt[t] = (t < PS_RP2 + 1) ? sqrt(x) : 0.0;     // DU2, DV2, U02, V02, RU2, RV2, RP2
+  } else if (t == 64 && crit) {
+    fin_dt = next_dt(total(PS_UMAX), total(PS_VMAX), a);
   }
+  __syncthreads();
+  if (t != 0) return;
+  double r[PS_N + 2];
+#pragma unroll
+  for (int q = 0; q < PS_N + 2; ++q) r[q] = fin_r[q];
   if (flush) {
     double* rec = a.rec + (size_t)((iter - 1) % a.rec_cap) * LDC_REC_LEN;
     rec[LDC_REC_Z] = 0.5 * r[PS_N];
@@ -910,22 +923,22 @@ __device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t) 
     a.ctrl[LDC_CTRL_FLUSHED] = iter;
   }
   if (crit) {
-    const double relu = sqrt(r[PS_DU2]) / (sqrt(r[PS_U02]) + 1e-12);
-    const double relv = sqrt(r[PS_DV2]) / (sqrt(r[PS_V02]) + 1e-12);
+    const double relu = fin_sqrt[PS_DU2] / (fin_sqrt[PS_U02] + 1e-12);
+    const double relv = fin_sqrt[PS_DV2] / (fin_sqrt[PS_V02] + 1e-12);
     // Python's max(a, b) returns a unless b > a: a NaN in relv is dropped, one in relu sticks
     const double rel = (relv > relu) ? relv : relu;
     double* rec = a.rec + (size_t)(iter % a.rec_cap) * LDC_REC_LEN;   // `iter` = 0-based index of this iteration
     rec[LDC_REC_REL] = rel;
-    rec[LDC_REC_RU] = sqrt(r[PS_RU2]);
-    rec[LDC_REC_RV] = sqrt(r[PS_RV2]);
-    rec[LDC_REC_RP] = sqrt(r[PS_RP2]);
+    rec[LDC_REC_RU] = fin_sqrt[PS_RU2];
+    rec[LDC_REC_RV] = fin_sqrt[PS_RV2];
+    rec[LDC_REC_RP] = fin_sqrt[PS_RP2];
     rec[LDC_REC_E] = 0.5 * r[PS_E];
     rec[LDC_REC_Z] = 0.0;
     rec[LDC_REC_P] = 0.0;
     rec[LDC_REC_DT] = a.scal[LDC_SCAL_DT];
     a.scal[LDC_SCAL_UMAX] = r[PS_UMAX];
     a.scal[LDC_SCAL_VMAX] = r[PS_VMAX];
-    a.scal[LDC_SCAL_DT] = next_dt(r[PS_UMAX], r[PS_VMAX], a);
+    a.scal[LDC_SCAL_DT] = fin_dt;
     a.ctrl[LDC_CTRL_ITER] = iter + 1;
     if (!a.with_diag) a.ctrl[LDC_CTRL_FLUSHED] = iter + 1;      // nothing to fold for this record
     if (iter >= a.warmup && rel < a.tol) a.ctrl[LDC_CTRL_DONE] = 1;
