@@ -186,11 +186,13 @@ def test_n256_short_run_vs_oracle():
     assert rel(rec[:, 6], np.array(Ps)) < 1e-9
 
 
-@pytest.mark.parametrize("N,Re", [(8, 50.0), (12, 50.0), (48, 100.0), (96, 400.0), (100, 400.0), (272, 1000.0)])
+@pytest.mark.parametrize("N,Re", [(8, 50.0), (12, 50.0), (48, 100.0), (96, 400.0), (100, 400.0), (272, 1000.0),
+                                  (128, 1000.0), (160, 400.0), (200, 1000.0), (240, 100.0)])
 def test_short_run_records_vs_oracle(N, Re):
     """Every history column against the oracle at sizes that place the index-(M-1) work differently:
     one tile holding all three jobs (N = 16 is in the fixtures), T = 3 (corner job on tile (0, 2)), T = 6,
-    sizes that are no multiple of 16, and a multiple of 16 beyond 256 (index M-1 inside the tiles)."""
+    sizes that are no multiple of 16, and a multiple of 16 beyond 256 (index M-1 inside the tiles); T = 8 and 16
+    take the XCD-patched tile order, T = 10, 13, 15 the plain one; 3 or 4 k-groups per wave."""
     K = 14 if N <= 100 else 12
     o = orc.OracleSG(N, Re)
     rows = []
