@@ -2,8 +2,9 @@
 //
 // Hot path of the Chebyshev P_N-P_{N-2} artificial-compressibility lid-driven-cavity
 // solver (reference: src/solvers/spectral/sg.py, src/solvers/base.py:202-330), written
-// for CDNA4: fp64 MFMA (v_mfma_f64_16x16x4_f64), 64-wide waves, one 4-wave work-group
-// per 16x16 output tile with the contraction index split over the four SIMDs.
+// for CDNA4: fp64 MFMA (v_mfma_f64_16x16x4_f64), 64-wide waves, one work-group per 16x16
+// output tile -- 8 waves in the RK stage kernel (2 per SIMD, split by derivative direction and by
+// quarter of the contraction index), 4 in the post / diagnostics kernels (one per SIMD).
 //
 // Layout recap (include/ldc_hip.h): every array is LD x LD doubles, row-major, zero
 // padded, element [ix][iy]; each field has a transposed copy.  With that, EVERY product
@@ -15,7 +16,7 @@
 //   d/dx  (Dx @ U)[i][j]   = sum_k Dx[i][k] * UT[j][k]
 //   d/dy  (U @ Dy^T)[i][j] = sum_k U [i][k] * Dy[j][k]
 //
-// MFMA lane maps (v_mfma_f64_16x16x4_f64; pinned by tests/test_gpu_mfma.py):
+// MFMA lane maps (v_mfma_f64_16x16x4_f64; pinned by tests/test_gpu_parity.py::test_mfma_lane_maps):
 //   A: lane l holds A[row l&15][k l>>4]      B: lane l holds B[k l>>4][col l&15]
 //   D: lane l, reg r holds D[row (l>>4)+4r][col l&15]
 // A lane loads 4 consecutive k (k0+4q .. k0+4q+3, q = l>>4) and feeds element s to the
