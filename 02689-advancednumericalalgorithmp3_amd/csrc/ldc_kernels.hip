@@ -588,7 +588,11 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   // joins, every group's MFMAs with vmcnt(0) -- which also waits for the prefetch just issued (all variants with
   // index-(M-1) handling had that; with the drain the loop waits with vmcnt(8..14) as intended).  Same-box A/B at
   // N=256: no drain 55.1, drain here 53.9, drain before the pointwise loads are issued 54.3 us per iteration.
-  if (EDGES) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), lgkmcnt / expcnt untouched
+  if (EDGES || BATCH) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), lgkmcnt / expcnt untouched
+  // Batched launches: the work-groups of a trial whose latch has fired leave HERE, before the K loop, so that a
+  // batch gets cheaper as its trials converge (trials of one batch can differ by 25 % in iteration count).  The
+  // wait above keeps the prologue's loads in front of this branch (a return any earlier gets them sunk below it).
+  if (BATCH && latched != 0) return;
   // ---- contraction over k: this wave's quarter, loads one group ahead (A/B ping-pong) --------
   v4d acc[NA];
 #pragma unroll
