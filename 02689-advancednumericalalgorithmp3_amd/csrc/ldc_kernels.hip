@@ -62,6 +62,36 @@ __device__ __forceinline__ T gl(const T* p, size_t i) {
   return ((const LDC_GLOBAL T*)p)[i];
 }
 
+// ---- coherent forms (COH): what the persistent trial kernel uses for every byte another work-group may have
+// written in the same launch.  Producer side: write-through (sc1) stores, every storing wave's s_waitcnt vmcnt(0),
+// the work-group barrier, ONE lane's agent-scope counter add.  Consumer side: ONE lane polls the counter with
+// sc1 loads, the work-group barrier, then EVERY load of handed-off bytes is an sc1 load to registers (or an sc1
+// LDS-direct load): sc1 loads bypass the CU's L1, which no other CU's store ever refreshes
+// (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility", valid forms, row 1).
+// 16-byte loads go through the buffer builtin (aux 16 = sc1): hipcc counts them in vmcnt like any load.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_rsrc(const double* base) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, -1, 0x00020000);
+}
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+template <bool COH>
+__device__ __forceinline__ v4d ldpk_t(const double* XK, int NB, int R, int G, int lane) {
+  if constexpr (!COH) {
+    return ldpk(XK, NB, R, G, lane);
+  } else {
+    const __amdgpu_buffer_rsrc_t r = raw_rsrc(XK);
+    const int off = ((((R * NB + G) << 6) + lane) * 4) * (int)sizeof(double);
+    const v2d_t lo = __builtin_bit_cast(v2d_t, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16));
+    const v2d_t hi = __builtin_bit_cast(v2d_t, __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, 16));
+    return (v4d){lo[0], lo[1], hi[0], hi[1]};
+  }
+}
+template <bool COH, typename T>
+__device__ __forceinline__ T gl_t(const T* p, size_t i) {
+  if constexpr (!COH) return gl(p, i);
+  else return __hip_atomic_load((const LDC_GLOBAL T*)p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Store of state that only LATER launches read.  wt != 0: agent-scope write-through (global_store ... sc1): the
 // bytes leave the XCD's L2 while the other tiles still compute instead of at the end-of-kernel write-back
 // (N=256: 4-7 MB dirty per stage launch, -3.3 us per iteration; neutral at N <= 64; non-temporal stores bought
@@ -70,9 +100,10 @@ __device__ __forceinline__ T gl(const T* p, size_t i) {
 // 16-byte form (p 16-byte aligned).  There is no 16-byte atomic store to lower from; an asm store is safe here (no
 // result register, nothing in the kernel reads these bytes back, s_endpgm completes outstanding stores).
 __device__ __forceinline__ void st_out2(double* p, double v0, double v1, int wt) {
-  typedef double v2d_t __attribute__((ext_vector_type(2)));
   const v2d_t v = {v0, v1};
-  if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"((LDC_GLOBAL v2d_t*)p), "v"(v) : "memory");
+  // (the trailing s_nop 1: hipcc pads no hazard inside an asm string, and the instruction after a store of more than
+  //  64 bits must not overwrite its data registers for two wait states)
+  if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"((LDC_GLOBAL v2d_t*)p), "v"(v) : "memory");
   else *(LDC_GLOBAL v2d_t*)p = v;
 }
 __device__ __forceinline__ void st_out(double* p, double v, int wt) {
@@ -233,7 +264,7 @@ constexpr int kStageThreads = 64 * kStageWaves;
 // (point 0 = kernel entry is taken unconditionally into t_entry and stored with point 1: a conditional store
 //  in the prologue would split the entry block, see tile_of_block)
 #define LDC_STAMP(k) do { if ((a.ablate & 64) && lane == 0) { \
-  double* st_ = a.dump[0] + ((size_t)blockIdx.x * kStageWaves + wv) * 8; \
+  double* st_ = a.dump[0] + ((size_t)bx * kStageWaves + wv) * 8; \
   st_[k] = (double)__builtin_amdgcn_s_memtime(); if ((k) == 1) st_[0] = (double)t_entry; } } while (0)
 constexpr int kEdgeRowDoubles = 6 * 4 * 16;    // per wave: 6 rows of index M-1 x 4 groups x 16 (tail needs T <= 16)
 constexpr size_t kLdsLimit = 160 * 1024;
@@ -291,29 +322,32 @@ struct ExtraFrags {    // operands of the fifth contraction: single-buffered (lo
 // (timing switch `ablate & 2`: every lane reads element 0 instead -- same instructions, no operand traffic;
 //  a branch around the loads would make the compiler wait for them at the join)
 // I, J: block row of the A / B operands; G: 16-k group
+template <bool COH>
 __device__ __forceinline__ void load_role(RoleFrags& f, const RoleOps& o, int NB, int I, int J, int G, int lane) {
   const int keep = (o.ablate & 2) ? 0 : 1;
   I *= keep; J *= keep; G *= keep; lane *= keep;
-  f.a0 = ldpk(o.A0, NB, I, G, lane); f.a1 = ldpk(o.A1, NB, I, G, lane);
-  f.b0 = ldpk(o.B0, NB, J, G, lane); f.b1 = ldpk(o.B1, NB, J, G, lane);
+  f.a0 = ldpk_t<COH>(o.A0, NB, I, G, lane); f.a1 = ldpk_t<COH>(o.A1, NB, I, G, lane);
+  f.b0 = ldpk_t<COH>(o.B0, NB, J, G, lane); f.b1 = ldpk_t<COH>(o.B1, NB, J, G, lane);
 }
 
+template <bool COH>
 __device__ __forceinline__ void load_extra(ExtraFrags& x, const RoleOps& o, int NB, int I, int J, int G, int lane) {
   const int keep = (o.ablate & 2) ? 0 : 1;
   I *= keep; J *= keep; G *= keep; lane *= keep;
   // both, always: a load that only one role issues makes the number of loads in flight path-dependent, and the
   // compiler then waits with vmcnt(0) before every group's MFMAs (prefetch included).  The operand a role does
   // not use (x4 = 1: a2, x4 = 2: b2) points at a panel it reads anyway (A0 / B0): a cache hit.  (Timing-neutral.)
-  x.a2 = ldpk(o.A2, NB, I, G, lane);
-  x.b2 = ldpk(o.B2, NB, J, G, lane);
+  x.a2 = ldpk_t<COH>(o.A2, NB, I, G, lane);
+  x.b2 = ldpk_t<COH>(o.B2, NB, J, G, lane);
 }
 
 // LDS-direct 16-byte load: lane l's 16 bytes land at lds_dst + 16*l bytes (lds_dst wave-uniform);
 // no registers, counted by vmcnt like any load (semantics pinned by tools/probes/dma_probe.hip)
 typedef double v2d __attribute__((ext_vector_type(2)));
+template <bool COH>
 __device__ __forceinline__ void dma16(const double* src, double* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, COH ? 16 : 0);   // aux 16 = sc1
 }
 
 template <bool GP, int NA>
@@ -453,18 +487,19 @@ struct StageLds {
 //        forms anyway, its enstrophy partial sums and the omega / omega^T arrays; 2 (stage 2) the two
 //        contractions Dx.omega, omega.Dy^T and the palinstrophy partial sums.  Both belong to the record
 //        of iteration n and are folded by the finalize block of the next post launch.
-template <bool GPV, bool LAST, bool DUMP, bool BATCH, int DIAG>
-__global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs a_val, const StageArgs* a_arr) {
-  // by value: with a reference into device memory (BATCH) every write-through store made the compiler re-load the
-  // fields it needs next (+3 us per launch)
-  const StageArgs a = BATCH ? a_arr[blockIdx.y] : a_val;
+// PERSIST: the body runs as one PHASE of the persistent trial kernel (trial_kernel below): `bx` / `nblk` stand in for
+//        blockIdx.x / gridDim.x, the latch, the step counter and dt come from the kernel's own control block
+//        (p_latched, p_step0, p_dt) instead of ctrl / scal, every load of state is a coherent (sc1) load and every
+//        store of it write-through, and no control word is written (the kernel keeps them in LDS until it ends).
+template <bool GPV, bool LAST, bool DUMP, bool BATCH, int DIAG, bool PERSIST>
+__device__ __forceinline__ void stage_body(const StageArgs a, const int bx, const int nblk, double* lds,
+                                           const int p_latched, const int p_step0, const double p_dt) {
   constexpr bool GP = GPV || (DIAG == 2);      // "has a fifth contraction" (grad p or grad omega)
   static_assert(!(GPV && DIAG == 2), "stage 2 of SG carries no pressure contraction");
   constexpr int VEL = (LAST || DUMP) ? 1 : (DIAG == 1 ? 2 : 0);   // what the nodes of index M-1 need here
   constexpr bool EDGES = GP || (VEL != 0);
   using L = StageLds<GP, EDGES>;
   constexpr int NA = L::NA;
-  extern __shared__ __attribute__((aligned(16))) double lds[];
   double* red = lds;
   const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 
@@ -473,7 +508,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   const int M = a.M, LD = a.LD, T = a.T, m1 = M - 1, NB = a.NB;
 
   int I, J;
-  tile_of_block((int)blockIdx.x, T, I, J);
+  tile_of_block(bx, T, I, J);
   const int r0 = 16 * I, c0 = 16 * J;
   // The nodes of index M-1 are spread over 2T+1 tiles, one job each (the VALU dot products of a job cost a
   // tile ~0.7 us; all three jobs in the corner tile made it the slowest of the launch by 2-3 us):
@@ -515,24 +550,24 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
     const double* s01 = sl ? o.row[1] : o.row[0];
     const double* s23 = sl ? o.row[3] : o.row[2];
     const double* s45 = sl ? o.row[5] : o.row[4];
-    if (live && needA && s01 != nullptr) dma16(s01 + off, erow);
-    if (live && (sl ? needB : needA) && s23 != nullptr) dma16(s23 + off, erow + 128);
-    if (live && needB && s45 != nullptr) dma16(s45 + off, erow + 256);
+    if (live && needA && s01 != nullptr) dma16<PERSIST>(s01 + off, erow);
+    if (live && (sl ? needB : needA) && s23 != nullptr) dma16<PERSIST>(s23 + off, erow + 128);
+    if (live && needB && s45 != nullptr) dma16<PERSIST>(s45 + off, erow + 256);
   }
 
   // ---- first fragments in flight before anything else ------------------------------------
   RoleFrags fa, fb;
   ExtraFrags fx;
-  load_role(fa, o, NB, I, J, ng > 0 ? gk(0) : 0, lane);
+  load_role<PERSIST>(fa, o, NB, I, J, ng > 0 ? gk(0) : 0, lane);
 
   // The latch, the step counter and dt are only READ here (scalar loads, nobody waits for them yet); the
   // latch is acted upon after the K loop.  An early `return` at this point made the compiler sink the
   // fragment loads below it: kernel arguments -> latch -> operand pointers -> fragments became four cold
   // misses in a row (~1.4 us before the first MFMA).  A latched launch now runs its K loop for nothing,
   // which only happens in the last partial batch of a solve.
-  const int latched = DUMP ? 0 : sload(a.ctrl + LDC_CTRL_DONE);
-  const int step0 = sload(a.ctrl + LDC_CTRL_STEP);
-  const double adt = a.alpha * sload(a.scal + LDC_SCAL_DT);
+  const int latched = PERSIST ? p_latched : (DUMP ? 0 : sload(a.ctrl + LDC_CTRL_DONE));
+  const int step0 = PERSIST ? p_step0 : sload(a.ctrl + LDC_CTRL_STEP);
+  const double adt = a.alpha * (PERSIST ? p_dt : sload(a.scal + LDC_SCAL_DT));
 
   // ---- pointwise operands of the epilogue, issued now so that they land under the MFMAs ----------
   // threads 0..255 own node (i, j) of the tile; in a tile with an index-(M-1) job threads 256.. own
@@ -555,31 +590,31 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   if (owner || edge_thr) {
     if (owner) {     // stage input at a tile node: from the packed twin (block (I, J), element (ti, tj))
       const size_t kin = ((size_t)(I * NB + J) << 8) + (size_t)((((tj >> 2) << 4) + ti) << 2) + (tj & 3);
-      uin = gl(a.UinK, kin);
-      vin = gl(a.VinK, kin);
+      uin = gl_t<PERSIST>(a.UinK, kin);
+      vin = gl_t<PERSIST>(a.VinK, kin);
     } else {         // node of index M-1: row-major forms (never rewritten by the tiles)
-      uin = gl(colnode ? a.UinT : a.Uin, colnode ? ijT : ij);
-      vin = gl(colnode ? a.VinT : a.Vin, colnode ? ijT : ij);
+      uin = gl_t<PERSIST>(colnode ? a.UinT : a.Uin, colnode ? ijT : ij);
+      vin = gl_t<PERSIST>(colnode ? a.VinT : a.Vin, colnode ? ijT : ij);
     }
     if (!DUMP) {
-      u0 = gl(colnode ? a.U0T : a.U0, colnode ? ijT : ij);
-      v0 = gl(colnode ? a.V0T : a.V0, colnode ? ijT : ij);
+      u0 = gl_t<PERSIST>(colnode ? a.U0T : a.U0, colnode ? ijT : ij);
+      v0 = gl_t<PERSIST>(colnode ? a.V0T : a.V0, colnode ? ijT : ij);
     }
-    if (owner && !DUMP && a.Pout != nullptr) p0 = gl(a.P0, ij);
+    if (owner && !DUMP && a.Pout != nullptr) p0 = gl_t<PERSIST>(a.P0, ij);
     if (!GPV && (owner || VEL == 1)) {
       const size_t ip = colnode ? (size_t)M * LD + i : ij;
-      px = gl(a.PX, ip); py = gl(a.PY, ip);
+      px = gl_t<PERSIST>(a.PX, ip); py = gl_t<PERSIST>(a.PY, ip);
     }
     if (a.tail) {
-      dxl = gl(a.DxL, i); d2xl = gl(a.D2xL, i); dyl = gl(a.DyL, j); d2yl = gl(a.D2yL, j);
-      ue = gl(a.Uin, (size_t)m1 * LD + j); ve = gl(a.Vin, (size_t)m1 * LD + j);    // east-wall row
-      un_ = gl(a.UinT, (size_t)m1 * LD + i); vn_ = gl(a.VinT, (size_t)m1 * LD + i);  // lid column, read along the transposed copy
-      if (DIAG == 2) { we = gl(a.W, (size_t)m1 * LD + j); wn = gl(a.WT, (size_t)m1 * LD + i); }
+      dxl = gl_t<PERSIST>(a.DxL, i); d2xl = gl_t<PERSIST>(a.D2xL, i); dyl = gl_t<PERSIST>(a.DyL, j); d2yl = gl_t<PERSIST>(a.D2yL, j);
+      ue = gl_t<PERSIST>(a.Uin, (size_t)m1 * LD + j); ve = gl_t<PERSIST>(a.Vin, (size_t)m1 * LD + j);    // east-wall row
+      un_ = gl_t<PERSIST>(a.UinT, (size_t)m1 * LD + i); vn_ = gl_t<PERSIST>(a.VinT, (size_t)m1 * LD + i);  // lid column, read along the transposed copy
+      if (DIAG == 2) { we = gl_t<PERSIST>(a.W, (size_t)m1 * LD + j); wn = gl_t<PERSIST>(a.WT, (size_t)m1 * LD + i); }
     }
-    lidv = gl(a.ulid, i);
+    lidv = gl_t<PERSIST>(a.ulid, i);
     // (only loaded here: their product is formed in the epilogue -- arithmetic on a loaded value at this point
     //  makes the wave wait for every load issued so far, first fragments included: +1.2 us before the K loop)
-    if (LAST || DIAG != 0) { wxi = gl(a.wx, i); wyj = gl(a.wy, j); }
+    if (LAST || DIAG != 0) { wxi = gl_t<PERSIST>(a.wx, i); wyj = gl_t<PERSIST>(a.wy, j); }
   }
 
   LDC_STAMP(1);
@@ -603,13 +638,13 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   // Loads one group ahead (A/B ping-pong); with the packed twins one group ahead is enough (the probe delivers
   // the whole 278 KB of a tile in ~1.9 us whatever the depth, profiles/r01_aql_probe.log).
   for (int n = 0; n < ng; n += 2) {
-    if (GP) load_extra(fx, o, NB, I, J, gk(n), lane);          // first: loads return in issue order
-    load_role(fb, o, NB, I, J, gk(n + 1 < ng ? n + 1 : n), lane);   // clamped: harmless reload
+    if (GP) load_extra<PERSIST>(fx, o, NB, I, J, gk(n), lane);          // first: loads return in issue order
+    load_role<PERSIST>(fb, o, NB, I, J, gk(n + 1 < ng ? n + 1 : n), lane);   // clamped: harmless reload
     mfma_role<GP, NA>(fa, fx, acc, a.ablate, o.x4);
     if (anyE && !(a.ablate & 4096)) edge_group<VEL, GP>(ea, fa, fx, o, erow, n, lane, rowE, colE, cornE);
     if (n + 1 < ng) {
-      if (GP) load_extra(fx, o, NB, I, J, gk(n + 1), lane);
-      load_role(fa, o, NB, I, J, gk(n + 2 < ng ? n + 2 : n + 1), lane);
+      if (GP) load_extra<PERSIST>(fx, o, NB, I, J, gk(n + 1), lane);
+      load_role<PERSIST>(fa, o, NB, I, J, gk(n + 2 < ng ? n + 2 : n + 1), lane);
       mfma_role<GP, NA>(fb, fx, acc, a.ablate, o.x4);
       if (anyE && !(a.ablate & 4096)) edge_group<VEL, GP>(ea, fb, fx, o, erow, n + 1, lane, rowE, colE, cornE);
     }
@@ -791,11 +826,13 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
       for (int m = 0; m < kStageWaves; ++m) x += red[lane + 64 * m];
       x = wave_sum(x);
       double* slab = (DIAG == 1 ? a.partZ0 : a.partP0) + (size_t)((step0 > 0 ? step0 - 1 : 0) & 1) * a.stride;
-      if (lane == 0) slab[(size_t)blockIdx.x * LDC_NPART] = x;
+      if (lane == 0) {
+        if (PERSIST) st_out(slab + (size_t)bx * LDC_NPART, x, 1); else slab[(size_t)bx * LDC_NPART] = x;
+      }
     }
-    if (DIAG == 2 && blockIdx.x == 0 && tid == 0) {      // Z and P partials of state `step0` are complete
+    if (!PERSIST && DIAG == 2 && bx == 0 && tid == 0) {      // Z and P partials of state `step0` are complete
       a.ctrl[LDC_CTRL_PDONE] = step0;
-      a.ctrl[LDC_CTRL_DROWS] = (int)gridDim.x;
+      a.ctrl[LDC_CTRL_DROWS] = nblk;
     }
   }
   if (LAST && !(a.ablate & 4)) {
@@ -806,24 +843,33 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
     red[PS_UMAX * kStageThreads + tid] = maxs[0];
     red[PS_VMAX * kStageThreads + tid] = maxs[1];
     __syncthreads();
-    double* dst = a.partials + (size_t)blockIdx.x * LDC_NPART;
+    double* dst = a.partials + (size_t)bx * LDC_NPART;
     {
       double x = 0.0;
 #pragma unroll
       for (int m = 0; m < kStageWaves; ++m) x += red[wv * kStageThreads + lane + 64 * m];
       x = wave_sum(x);
-      if (lane == 0) dst[wv] = x;       // kStageWaves == PS_NSUM
+      if (lane == 0) { if (PERSIST) st_out(dst + wv, x, 1); else dst[wv] = x; }       // kStageWaves == PS_NSUM
     }
     if (wv < 2) {
       double x = 0.0;
 #pragma unroll
       for (int m = 0; m < kStageWaves; ++m) x = fmax(x, red[(PS_NSUM + wv) * kStageThreads + lane + 64 * m]);
       x = wave_max(x);
-      if (lane == 0) dst[PS_NSUM + wv] = x;
+      if (lane == 0) { if (PERSIST) st_out(dst + PS_NSUM + wv, x, 1); else dst[PS_NSUM + wv] = x; }
     }
-    if (blockIdx.x == 0 && tid == 0) a.ctrl[LDC_CTRL_STEP] = step0 + 1;   // one more state update done
+    if (!PERSIST && bx == 0 && tid == 0) a.ctrl[LDC_CTRL_STEP] = step0 + 1;   // one more state update done
   }
   LDC_STAMP(6);
+}
+
+template <bool GPV, bool LAST, bool DUMP, bool BATCH, int DIAG>
+__global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs a_val, const StageArgs* a_arr) {
+  // by value: with a reference into device memory (BATCH) every write-through store made the compiler re-load the
+  // fields it needs next (+3 us per launch)
+  const StageArgs a = BATCH ? a_arr[blockIdx.y] : a_val;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  stage_body<GPV, LAST, DUMP, BATCH, DIAG, false>(a, (int)blockIdx.x, (int)gridDim.x, lds, 0, 0, 0.0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -854,48 +900,67 @@ __device__ __forceinline__ double next_dt(double umax, double vmax, const FinalA
   return a.cfl / (lx + ly);
 }
 
-// all kThreads threads of one block call this; sm holds kThreads * (PS_N + 2) doubles
-__device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t) {
+// Control block of one trial inside the persistent trial kernel (LDS; every work-group keeps its own, identical copy:
+// they all fold the same partial sums in the same order).  Mirrors ctrl[] / scal[] of the launch-per-stage path.
+struct TrialState {
+  int done, iter, step, flushed, pdone, drows;
+  int abort;                 // a bounded spin of a grid barrier gave up (LDC_E_SYNC): every thread leaves
+  double dt, umax, vmax;
+};
+
+// Threads 0 .. kThreads-1 of one block do the work, sm holds kThreads * (PS_N + 2) doubles.
+// PERSIST = false: the finalize block of a post launch / the finalize kernel (256 threads, control words in ctrl/scal).
+// PERSIST = true : a phase of the persistent trial kernel.  ALL threads of the (larger) work-group call it (the
+//   barriers inside are the work-group's), the control words live in *S, the partial sums other work-groups wrote
+//   in this launch are read with coherent loads, and only the work-group with `writer` set stores the record.
+template <bool PERSIST>
+__device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t, TrialState* S, bool writer) {
   __shared__ int fin_state[6];       // one reader: the decision below guards barriers
-  if (t == 0) {
-    fin_state[0] = a.ctrl[LDC_CTRL_DONE]; fin_state[1] = a.ctrl[LDC_CTRL_ITER];
-    fin_state[2] = a.ctrl[LDC_CTRL_STEP]; fin_state[3] = a.ctrl[LDC_CTRL_FLUSHED];
-    fin_state[4] = a.ctrl[LDC_CTRL_PDONE]; fin_state[5] = a.ctrl[LDC_CTRL_DROWS];
+  if (!PERSIST) {
+    if (t == 0) {
+      fin_state[0] = a.ctrl[LDC_CTRL_DONE]; fin_state[1] = a.ctrl[LDC_CTRL_ITER];
+      fin_state[2] = a.ctrl[LDC_CTRL_STEP]; fin_state[3] = a.ctrl[LDC_CTRL_FLUSHED];
+      fin_state[4] = a.ctrl[LDC_CTRL_PDONE]; fin_state[5] = a.ctrl[LDC_CTRL_DROWS];
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  const int done = fin_state[0], iter = fin_state[1], step = fin_state[2], flushed = fin_state[3];
-  const int pdone = fin_state[4], drows = fin_state[5];
+  const int done = PERSIST ? S->done : fin_state[0], iter = PERSIST ? S->iter : fin_state[1];
+  const int step = PERSIST ? S->step : fin_state[2], flushed = PERSIST ? S->flushed : fin_state[3];
+  const int pdone = PERSIST ? S->pdone : fin_state[4], drows = PERSIST ? S->drows : fin_state[5];
   // record iter-1 lacks Z, P, and the partial sums of state `iter` (its end state) are complete
   const bool flush = a.with_diag && (flushed < iter) && (pdone >= iter);
   const bool crit = a.do_critical && !done && (step > iter);       // iteration `iter` awaits its record
   if (!flush && !crit) return;
+  const bool active = t < kThreads;
   double v[PS_N + 2];
 #pragma unroll
   for (int q = 0; q < PS_N + 2; ++q) v[q] = 0.0;
-  if (crit) {
+  if (crit && active) {
     for (int r = t; r < a.nblk4; r += kThreads) {
       const double* p = a.part4 + (size_t)r * LDC_NPART;
 #pragma unroll
-      for (int q = 0; q < PS_NSUM; ++q) v[q] += p[q];
-      v[PS_UMAX] = fmax(v[PS_UMAX], p[PS_UMAX]);
-      v[PS_VMAX] = fmax(v[PS_VMAX], p[PS_VMAX]);
+      for (int q = 0; q < PS_NSUM; ++q) v[q] += gl_t<PERSIST>(p, q);
+      v[PS_UMAX] = fmax(v[PS_UMAX], gl_t<PERSIST>(p, PS_UMAX));
+      v[PS_VMAX] = fmax(v[PS_VMAX], gl_t<PERSIST>(p, PS_VMAX));
     }
   }
-  if (flush) {
+  if (flush && active) {
     // (loading these rows speculatively, together with the control words above, was measured: +0.7 us per iteration)
     const int par = (iter - 1) & 1;
     const double* pz = a.partZ0 + (size_t)par * a.stride;
     const double* pp = a.partP0 + (size_t)par * a.stride;
-    for (int r = t; r < drows; r += kThreads) v[PS_N] += pz[(size_t)r * LDC_NPART];
-    for (int r = t; r < drows; r += kThreads) v[PS_N + 1] += pp[(size_t)r * LDC_NPART];
+    for (int r = t; r < drows; r += kThreads) v[PS_N] += gl_t<PERSIST>(pz, (size_t)r * LDC_NPART);
+    for (int r = t; r < drows; r += kThreads) v[PS_N + 1] += gl_t<PERSIST>(pp, (size_t)r * LDC_NPART);
   }
   // wave totals on DPP moves, then one value per wave through LDS (fixed order)
   constexpr int NW = kThreads / 64;
+  if (active) {
 #pragma unroll
-  for (int q = 0; q < PS_N + 2; ++q) {
-    const bool is_max = (q == PS_UMAX || q == PS_VMAX);
-    v[q] = is_max ? wave_max(v[q]) : wave_sum(v[q]);
-    if ((t & 63) == 0) sm[q * NW + (t >> 6)] = v[q];
+    for (int q = 0; q < PS_N + 2; ++q) {
+      const bool is_max = (q == PS_UMAX || q == PS_VMAX);
+      v[q] = is_max ? wave_max(v[q]) : wave_sum(v[q]);
+      if ((t & 63) == 0) sm[q * NW + (t >> 6)] = v[q];
+    }
   }
   __syncthreads();
   // Cross-wave totals, their square roots and the next dt by SEPARATE lanes, in parallel: this block is the critical
@@ -917,44 +982,58 @@ __device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t) 
     fin_dt = next_dt(total(PS_UMAX), total(PS_VMAX), a);
   }
   __syncthreads();
-  if (t != 0) return;
-  double r[PS_N + 2];
+  if (t == 0) {
+    double r[PS_N + 2];
 #pragma unroll
-  for (int q = 0; q < PS_N + 2; ++q) r[q] = fin_r[q];
-  if (flush) {
-    double* rec = a.rec + (size_t)((iter - 1) % a.rec_cap) * LDC_REC_LEN;
-    rec[LDC_REC_Z] = 0.5 * r[PS_N];
-    rec[LDC_REC_P] = 0.5 * r[PS_N + 1];
-    a.ctrl[LDC_CTRL_FLUSHED] = iter;
+    for (int q = 0; q < PS_N + 2; ++q) r[q] = fin_r[q];
+    if (flush) {
+      if (writer) {
+        double* rec = a.rec + (size_t)((iter - 1) % a.rec_cap) * LDC_REC_LEN;
+        rec[LDC_REC_Z] = 0.5 * r[PS_N];
+        rec[LDC_REC_P] = 0.5 * r[PS_N + 1];
+      }
+      if (PERSIST) S->flushed = iter; else a.ctrl[LDC_CTRL_FLUSHED] = iter;
+    }
+    if (crit) {
+      const double relu = fin_sqrt[PS_DU2] / (fin_sqrt[PS_U02] + 1e-12);
+      const double relv = fin_sqrt[PS_DV2] / (fin_sqrt[PS_V02] + 1e-12);
+      // Python's max(a, b) returns a unless b > a: a NaN in relv is dropped, one in relu sticks
+      const double rel = (relv > relu) ? relv : relu;
+      if (writer) {
+        double* rec = a.rec + (size_t)(iter % a.rec_cap) * LDC_REC_LEN;   // `iter` = 0-based index of this iteration
+        rec[LDC_REC_REL] = rel;
+        rec[LDC_REC_RU] = fin_sqrt[PS_RU2];
+        rec[LDC_REC_RV] = fin_sqrt[PS_RV2];
+        rec[LDC_REC_RP] = fin_sqrt[PS_RP2];
+        rec[LDC_REC_E] = 0.5 * r[PS_E];
+        rec[LDC_REC_Z] = 0.0;
+        rec[LDC_REC_P] = 0.0;
+        rec[LDC_REC_DT] = PERSIST ? S->dt : a.scal[LDC_SCAL_DT];
+      }
+      const int latch = (iter >= a.warmup && rel < a.tol) ? 1
+                        : (a.nan_guard && !(fabs(rel) <= 1.79769313486231570815e308)) ? 2 : 0;
+      if (PERSIST) {
+        S->umax = r[PS_UMAX]; S->vmax = r[PS_VMAX]; S->dt = fin_dt;
+        S->iter = iter + 1;
+        if (!a.with_diag) S->flushed = iter + 1;
+        if (latch) S->done = latch;
+      } else {
+        a.scal[LDC_SCAL_UMAX] = r[PS_UMAX];
+        a.scal[LDC_SCAL_VMAX] = r[PS_VMAX];
+        a.scal[LDC_SCAL_DT] = fin_dt;
+        a.ctrl[LDC_CTRL_ITER] = iter + 1;
+        if (!a.with_diag) a.ctrl[LDC_CTRL_FLUSHED] = iter + 1;      // nothing to fold for this record
+        if (latch) a.ctrl[LDC_CTRL_DONE] = latch;
+      }
+    }
   }
-  if (crit) {
-    const double relu = fin_sqrt[PS_DU2] / (fin_sqrt[PS_U02] + 1e-12);
-    const double relv = fin_sqrt[PS_DV2] / (fin_sqrt[PS_V02] + 1e-12);
-    // Python's max(a, b) returns a unless b > a: a NaN in relv is dropped, one in relu sticks
-    const double rel = (relv > relu) ? relv : relu;
-    double* rec = a.rec + (size_t)(iter % a.rec_cap) * LDC_REC_LEN;   // `iter` = 0-based index of this iteration
-    rec[LDC_REC_REL] = rel;
-    rec[LDC_REC_RU] = fin_sqrt[PS_RU2];
-    rec[LDC_REC_RV] = fin_sqrt[PS_RV2];
-    rec[LDC_REC_RP] = fin_sqrt[PS_RP2];
-    rec[LDC_REC_E] = 0.5 * r[PS_E];
-    rec[LDC_REC_Z] = 0.0;
-    rec[LDC_REC_P] = 0.0;
-    rec[LDC_REC_DT] = a.scal[LDC_SCAL_DT];
-    a.scal[LDC_SCAL_UMAX] = r[PS_UMAX];
-    a.scal[LDC_SCAL_VMAX] = r[PS_VMAX];
-    a.scal[LDC_SCAL_DT] = fin_dt;
-    a.ctrl[LDC_CTRL_ITER] = iter + 1;
-    if (!a.with_diag) a.ctrl[LDC_CTRL_FLUSHED] = iter + 1;      // nothing to fold for this record
-    if (iter >= a.warmup && rel < a.tol) a.ctrl[LDC_CTRL_DONE] = 1;
-    else if (a.nan_guard && !(fabs(rel) <= 1.79769313486231570815e308)) a.ctrl[LDC_CTRL_DONE] = 2;
-  }
+  if (PERSIST) __syncthreads();      // *S is complete for every thread of this work-group
 }
 
 template <bool BATCH>
 __global__ __launch_bounds__(kThreads) void finalize_kernel(const FinalArgs a_val, const FinalArgs* a_arr) {
   __shared__ double sm[kThreads * (PS_N + 2)];
-  fin_work(BATCH ? a_arr[blockIdx.y] : a_val, sm, threadIdx.x);
+  fin_work<false>(BATCH ? a_arr[blockIdx.y] : a_val, sm, threadIdx.x, nullptr, true);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -984,7 +1063,7 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int M = a.M, LD = a.LD, T = a.T, nt = T * T, m1 = M - 1;
   int b = (int)blockIdx.x;
-  if (b == a.fin_block) { fin_work(a.fin, red, tid); return; }
+  if (b == a.fin_block) { fin_work<false>(a.fin, red, tid, nullptr, true); return; }
   // T tiles: the operand fragments of this wave's first four k-groups go out BEFORE the gate below (harmless
   // reads); behind it every thread used to sit through a cold miss for two control words and a barrier before its
   // first load, and then through one exposed load latency per group (-0.6 us per iteration at N=64, neutral at 256).
@@ -1137,6 +1216,232 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
       }
     }
     block_reduce_store<1, 0>(sums, dummy, red, partZ + (size_t)(nt + b) * LDC_NPART, lane, wv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// persistent trial kernel: every iteration of one trial inside ONE launch
+// ---------------------------------------------------------------------------------------
+// A trial of T x T tiles with T*T work-groups (at most one per CU, all resident) needs no launch boundary between its
+// RK stages: work-group (I, J) keeps its tile for the whole launch and the stages are separated by a counter barrier
+// among the trial's own work-groups.  What a launch-per-stage iteration pays per stage at small N -- a dependent
+// dispatch, the ramp of a new grid, cold kernel-argument and operand misses: five launches of ~7 us for 16 work-groups
+// at N = 64 -- shrinks to one barrier (an atomic add and a poll) per phase.  Data crosses work-groups in the form the
+// guide measures as valid without fences (MI355X_MICROARCH.md, visibility, valid forms row 1): write-through (sc1)
+// stores, every storing wave's vmcnt(0), work-group barrier, one lane's agent-scope add; one lane's sc1 poll,
+// work-group barrier, sc1 loads only.  The arithmetic is the launch path's, instruction for instruction
+// (stage_body / fin_work with PERSIST, post_phase = the T tiles of post_kernel), so records and fields are
+// bit-identical to it (tests/test_gpu_persistent.py).
+//
+// Phases of one iteration: stage 1 | stage 2 | stage 3 | stage 4 | finalize (EVERY work-group folds the partial sums
+// itself, in the same fixed order: dt and the latch need no broadcast) + pressure transforms; in smoother mode a
+// transform phase follows each of stages 1-3 as well.  A barrier closes every phase.
+struct TrialArgs {
+  StageArgs st[4];
+  PostArgs post;                 // transforms of p^(n+1); post.fin: the finalize arguments
+  const double* Pst[3];          // smoother mode: the stage pressure whose transforms follow stage 1, 2, 3 (PA, PB, PA)
+  const double* PstK[3];
+  int n_iters;
+  unsigned* sync;                // [0] arrival counter, [LDC_SYNC_GIVEUP] set when a spin gave up; zeroed before the launch
+  double* stamps;                // timing experiments (ldc_debug_stamps): 64 doubles per work-group, or null
+};
+static_assert(sizeof(TrialArgs) <= 4096, "TrialArgs must fit the kernel-argument segment");
+
+constexpr unsigned long long kSpinLimitTicks = 200000000ull;    // 2 s of the 100 MHz s_memrealtime counter
+
+// Barrier among the `nwg` work-groups of this launch; `phase` counts the barriers passed (monotonic counter: no reset,
+// no generation flip).  Returns false when the wait was given up (a peer is not resident or has left): every thread
+// of the work-group sees the same answer and the kernel ends.
+__device__ __forceinline__ bool grid_sync(unsigned* sync, unsigned& phase, unsigned nwg, int tid, TrialState* S) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have left
+  __syncthreads();
+  ++phase;
+  if (tid == 0) {
+    LDC_GLOBAL unsigned* ctr = (LDC_GLOBAL unsigned*)sync;
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = phase * nwg;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinLimitTicks) {
+        S->abort = 1;
+        __hip_atomic_store(ctr + LDC_SYNC_GIVEUP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  return S->abort == 0;
+}
+
+// wave-cooperative dot product, `a` written by other work-groups in this launch
+__device__ __forceinline__ double dot_rows_coh(const double* a, const double* b, int n, int lane) {
+  double s = 0.0;
+  for (int k = lane; k < n; k += 64) s += gl_t<true>(a, (size_t)k) * b[k];
+  return wave_sum(s);
+}
+
+// T1T / T2T of the pressure array P (packed twin PK) as a phase of the persistent kernel: tile (I, J) by waves 0-3
+// with the K split, the order of the sums and the stores of post_kernel's T tiles; the rows of index M-1 (tail) by
+// waves 4-7, one wave per k like post_kernel's edge blocks.  All kStageThreads threads call.
+__device__ __forceinline__ void post_phase(const PostArgs& a, const double* P, const double* PK, int bx, int nblk,
+                                           double* red, int tid) {
+  const int lane = tid & 63, wv = tid >> 6;
+  const int M = a.M, LD = a.LD, T = a.T, m1 = M - 1;
+  const bool tile_wave = wv < kWaves;
+  int I, J;
+  tile_of_block(bx, T, I, J);
+  const int r0 = 16 * I, c0 = 16 * J;
+  if (tile_wave) {
+    v4d acc[2] = {(v4d){0, 0, 0, 0}, (v4d){0, 0, 0, 0}};
+    for (int g = wv; g < T; g += kWaves) {
+      const v4d gP = ldpk_t<true>(PK, a.NB, I, g, lane);
+      const v4d gI = ldpk_t<true>(a.IyFK, a.NB, J, g, lane), gG = ldpk_t<true>(a.GyFK, a.NB, J, g, lane);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[0] = MFMA_F64(gP[s], gI[s], acc[0]);
+        acc[1] = MFMA_F64(gP[s], gG[s], acc[1]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wv * 2 + q) * 4 + r) * 64 + lane] = acc[q][r];
+  } else if (a.tail) {
+    for (int k = bx * kWaves + (wv - kWaves); k < M; k += nblk * kWaves) {
+      const double* pk = P + (size_t)k * LD;
+      const double t1 = dot_rows_coh(pk, a.IyF + (size_t)m1 * LD, M, lane);
+      const double t2 = dot_rows_coh(pk, a.GyF + (size_t)m1 * LD, M, lane);
+      if (lane == 0) { st_out(a.T1T + (size_t)m1 * LD + k, t1, 1); st_out(a.T2T + (size_t)m1 * LD + k, t2, 1); }
+    }
+  }
+  __syncthreads();
+  double s[2] = {0.0, 0.0};
+  if (tile_wave) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      double x = red[((0 * 2 + q) * 4 + wv) * 64 + lane];
+      x += red[((1 * 2 + q) * 4 + wv) * 64 + lane];
+      x += red[((2 * 2 + q) * 4 + wv) * 64 + lane];
+      x += red[((3 * 2 + q) * 4 + wv) * 64 + lane];
+      s[q] = x;
+    }
+  }
+  __syncthreads();
+  double* t1 = red;
+  double* t2 = red + 16 * 17;
+  if (tile_wave) {
+    const int ti = 4 * wv + (lane >> 4), tj = lane & 15;
+    t1[ti * 17 + tj] = s[0];
+    t2[ti * 17 + tj] = s[1];
+  }
+  __syncthreads();
+  if (tile_wave) {
+    const int tr = tid >> 4, tc = tid & 15;
+    const size_t o = (size_t)(c0 + tr) * LD + r0 + tc;
+    const bool ok = (c0 + tr < M) && (r0 + tc < M);
+    st_out(a.T1T + o, ok ? t1[tc * 17 + tr] : 0.0, 1);
+    st_out(a.T2T + o, ok ? t2[tc * 17 + tr] : 0.0, 1);
+    const int pl = tid >> 2, pr = pl & 15, pc = 4 * (pl >> 4) + (tid & 3);
+    const size_t kbT = ((size_t)(J * a.NB + I) << 8) + tid;
+    const bool okp = (c0 + pr < M) && (r0 + pc < M);
+    st_out(a.T1TK + kbT, okp ? t1[pc * 17 + pr] : 0.0, 1);
+    st_out(a.T2TK + kbT, okp ? t2[pc * 17 + pr] : 0.0, 1);
+  }
+}
+
+// One phase's argument block out of the kernel-argument segment, by value, AT the phase: read through a laundered
+// pointer so that the loads are neither hoisted out of the iteration loop nor all issued at kernel entry (four stage
+// blocks of ~80 pointers each held live across the loop cost ~440 SGPR and ~340 VGPR spills).
+typedef const __attribute__((address_space(4))) char* kernarg_ptr;
+template <typename T>
+__device__ __forceinline__ T phase_args(kernarg_ptr& base, size_t offset) {
+  asm volatile("" : "+s"(base));
+  T t;
+  __builtin_memcpy(&t, base + offset, sizeof(T));
+  return t;
+}
+#define LDC_TRIAL_ARG(T, member) phase_args<T>(kargs, __builtin_offsetof(TrialArgs, member))
+
+// SP: smoother mode (every stage differentiates its own stage pressure; FSG levels)   DIAGV: fused omega / Z / P
+template <bool SP, bool DIAGV>
+__global__ __launch_bounds__(kStageThreads, 2) void trial_kernel(const TrialArgs) {
+  static_assert(!(SP && DIAGV), "the smoother carries no diagnostics");
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ TrialState S;
+  const int tid = threadIdx.x, bx = (int)blockIdx.x, nblk = (int)gridDim.x;
+  kernarg_ptr kargs = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();     // TrialArgs is the only argument
+  const int n_iters = LDC_TRIAL_ARG(int, n_iters);
+  unsigned* const sync = LDC_TRIAL_ARG(unsigned*, sync);
+  // timing experiments: cycle stamps (s_memtime) of the LAST iteration's phase boundaries, thread 0 of every work-group
+  double* const stamps = LDC_TRIAL_ARG(double*, stamps);
+#define LDC_TSTAMP(k) do { if (stamps != nullptr && tid == 0 && it == n_iters - 1) \
+    stamps[(size_t)bx * 64 + (k)] = (double)__builtin_amdgcn_s_memtime(); } while (0)
+  {
+    const FinalArgs fa = LDC_TRIAL_ARG(FinalArgs, post.fin);
+    if (tid == 0) {
+      S.done = fa.ctrl[LDC_CTRL_DONE]; S.iter = fa.ctrl[LDC_CTRL_ITER]; S.step = fa.ctrl[LDC_CTRL_STEP];
+      S.flushed = fa.ctrl[LDC_CTRL_FLUSHED]; S.pdone = fa.ctrl[LDC_CTRL_PDONE]; S.drows = fa.ctrl[LDC_CTRL_DROWS];
+      S.dt = fa.scal[LDC_SCAL_DT]; S.umax = fa.scal[LDC_SCAL_UMAX]; S.vmax = fa.scal[LDC_SCAL_VMAX];
+      S.abort = 0;
+    }
+  }
+  __syncthreads();
+  unsigned phase = 0;
+  constexpr int D1 = DIAGV ? 1 : 0, D2 = DIAGV ? 2 : 0;
+  // the transforms of one pressure array as a phase (smoother mode: PA / PB / PA after stages 1-3; always: P)
+  auto transforms = [&](int which) {
+    const PostArgs pq = LDC_TRIAL_ARG(PostArgs, post);
+    const double* P = which < 0 ? pq.P : LDC_TRIAL_ARG(const double*, Pst[which < 0 ? 0 : which]);
+    const double* PK = which < 0 ? pq.PK : LDC_TRIAL_ARG(const double*, PstK[which < 0 ? 0 : which]);
+    post_phase(pq, P, PK, bx, nblk, lds, tid);
+  };
+  for (int it = 0; it < n_iters; ++it) {
+    if (S.done != 0) break;                      // every work-group holds the same latch
+    const int step0 = S.step;
+    const double dt = S.dt;
+    LDC_TSTAMP(0);
+    stage_body<true, false, false, false, D1, true>(LDC_TRIAL_ARG(StageArgs, st[0]), bx, nblk, lds, 0, step0, dt);
+    LDC_TSTAMP(1);
+    if (!grid_sync(sync, phase, nblk, tid, &S)) return;
+    LDC_TSTAMP(2);
+    if (SP) {
+      transforms(0);
+      if (!grid_sync(sync, phase, nblk, tid, &S)) return;
+    }
+    stage_body<SP, false, false, false, D2, true>(LDC_TRIAL_ARG(StageArgs, st[1]), bx, nblk, lds, 0, step0, dt);
+    if (DIAGV && tid == 0) { S.pdone = step0; S.drows = nblk; }     // Z and P partials of state `step0` are complete
+    LDC_TSTAMP(3);
+    if (!grid_sync(sync, phase, nblk, tid, &S)) return;
+    LDC_TSTAMP(4);
+    if (SP) {
+      transforms(1);
+      if (!grid_sync(sync, phase, nblk, tid, &S)) return;
+    }
+    stage_body<SP, false, false, false, 0, true>(LDC_TRIAL_ARG(StageArgs, st[2]), bx, nblk, lds, 0, step0, dt);
+    LDC_TSTAMP(5);
+    if (!grid_sync(sync, phase, nblk, tid, &S)) return;
+    LDC_TSTAMP(6);
+    if (SP) {
+      transforms(2);
+      if (!grid_sync(sync, phase, nblk, tid, &S)) return;
+    }
+    stage_body<SP, true, false, false, 0, true>(LDC_TRIAL_ARG(StageArgs, st[3]), bx, nblk, lds, 0, step0, dt);
+    if (tid == 0) S.step = step0 + 1;            // one more state update done
+    LDC_TSTAMP(7);
+    if (!grid_sync(sync, phase, nblk, tid, &S)) return;
+    LDC_TSTAMP(8);
+    fin_work<true>(LDC_TRIAL_ARG(FinalArgs, post.fin), lds, tid, &S, bx == 0);
+    LDC_TSTAMP(9);
+    transforms(-1);
+    LDC_TSTAMP(10);
+    if (it + 1 < n_iters && !grid_sync(sync, phase, nblk, tid, &S)) return;
+  }
+  if (bx == 0 && tid == 0) {
+    const FinalArgs fa = LDC_TRIAL_ARG(FinalArgs, post.fin);
+    fa.ctrl[LDC_CTRL_DONE] = S.done; fa.ctrl[LDC_CTRL_ITER] = S.iter; fa.ctrl[LDC_CTRL_STEP] = S.step;
+    fa.ctrl[LDC_CTRL_FLUSHED] = S.flushed; fa.ctrl[LDC_CTRL_PDONE] = S.pdone; fa.ctrl[LDC_CTRL_DROWS] = S.drows;
+    fa.scal[LDC_SCAL_DT] = S.dt; fa.scal[LDC_SCAL_UMAX] = S.umax; fa.scal[LDC_SCAL_VMAX] = S.vmax;
   }
 }
 
@@ -1398,6 +1703,7 @@ __global__ __launch_bounds__(kThreads) void mfma_peak_kernel(double* sink, int i
 // =======================================================================================
 struct ldc_solver {
   ldc_problem p;
+  int device;        // HIP device that was current at ldc_solver_create: every launch of this handle belongs there
   int nt;            // T*T
   int n_edge_blocks; // blocks of 4 edge nodes (tail case), else 0
   int n_pedge_blocks;
@@ -1406,6 +1712,8 @@ struct ldc_solver {
   double* stamps;            // ldc_debug_stamps
   hipGraphExec_t graph[2];   // [with_diagnostics]
   hipStream_t capture_stream;
+  int persist_mode;          // -1 auto, 0 launch per stage, 1 persistent trial kernel
+  int n_cus;                 // compute units of the handle's device
 };
 
 
@@ -1493,20 +1801,32 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
   return a;
 }
 
+// dynamic LDS above 64 KiB has to be enabled per kernel and device (hipFuncSetAttribute).  The library keeps no
+// process-wide state: ldc_solver_create / ldc_batch_create do it for every variant on the device that is current
+// there (the handle's device, checked again at every enqueue), so a launch itself touches nothing but its arguments.
+template <bool GP, bool LAST, bool DUMP, bool BATCH, int DIAG>
+int enable_stage_lds() {
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(stage_kernel<GP, LAST, DUMP, BATCH, DIAG>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+}
+template <bool BATCH>
+int enable_stage_lds_all() {
+  int e;
+  if ((e = enable_stage_lds<true, false, false, BATCH, 0>()) != 0) return e;
+  if ((e = enable_stage_lds<true, true, false, BATCH, 0>()) != 0) return e;
+  if ((e = enable_stage_lds<true, false, false, BATCH, 1>()) != 0) return e;
+  if ((e = enable_stage_lds<false, false, false, BATCH, 2>()) != 0) return e;
+  if ((e = enable_stage_lds<false, false, false, BATCH, 0>()) != 0) return e;
+  if ((e = enable_stage_lds<false, true, false, BATCH, 0>()) != 0) return e;
+  if (!BATCH && (e = enable_stage_lds<true, false, true, false, 0>()) != 0) return e;
+  return 0;
+}
+
 template <bool GP, bool LAST, bool DUMP, bool BATCH, int DIAG>
 int launch_stage_kernel(const StageArgs& a, const StageArgs* arr, int nt, int nbatch, hipStream_t st) {
-  static bool attr_set[64] = {};   // dynamic LDS above 64 KiB must be enabled once per kernel and device
   auto kern = stage_kernel<GP, LAST, DUMP, BATCH, DIAG>;
   constexpr size_t lds_bytes = StageLds<GP || DIAG == 2, GP || DIAG != 0 || LAST || DUMP>::BYTES;
   static_assert(lds_bytes <= kLdsLimit, "stage kernel LDS");
-  int dev = 0;
-  HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64) return LDC_E_ARG;
-  if (!attr_set[dev]) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)kLdsLimit));
-    attr_set[dev] = true;
-  }
   hipLaunchKernelGGL(kern, dim3(nt, nbatch), dim3(kStageThreads), lds_bytes, st, a, arr);
   return (int)hipGetLastError();
 }
@@ -1629,6 +1949,64 @@ int launch_closing_diagnostics(ldc_solver* s, hipStream_t st) {
   return launch_finalize(s, 1, 0, st);
 }
 
+// ---- persistent trial kernel ------------------------------------------------------------------------------
+constexpr size_t kTrialLdsBytes = StageLds<true, true>::BYTES;     // the largest carve of the stage variants
+static_assert(kTrialLdsBytes <= kLdsLimit, "trial kernel LDS");
+static_assert(kTrialLdsBytes >= sizeof(double) * kThreads * (PS_N + 2), "finalize scratch fits");
+
+int enable_trial_lds() {
+  const void* k[3] = {reinterpret_cast<const void*>(trial_kernel<false, false>),
+                      reinterpret_cast<const void*>(trial_kernel<false, true>),
+                      reinterpret_cast<const void*>(trial_kernel<true, false>)};
+  for (const void* f : k) {
+    // (what the launch asks for, not the 160 KiB limit: the kernel also has a few static words of LDS)
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrialLdsBytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+
+// every work-group of a trial must be resident at once (one per CU: the LDS carve allows no second one)
+bool persistent_available(const ldc_solver* s) {
+  return s->p.sync != nullptr && s->nt <= s->n_cus && s->ablate == 0;
+}
+bool use_persistent(const ldc_solver* s) {
+  if (s->persist_mode == 0 || !persistent_available(s)) return false;
+  return s->persist_mode == 1 || s->nt <= LDC_PERSIST_AUTO_TILES;
+}
+
+TrialArgs make_trial_args(const ldc_solver* s, int n_iters, int with_diag) {
+  TrialArgs ta;
+  memset(&ta, 0, sizeof(ta));
+  for (int k = 0; k < 4; ++k) {
+    ta.st[k] = make_stage_args(s, k);
+    ta.st[k].wt = 1;              // every store of state is write-through: it is what publishes it
+    ta.st[k].ablate = s->stamps ? 64 : 0;     // timing experiments: per-wave stamps of stage k behind the phase stamps
+    ta.st[k].dump[0] = s->stamps ? s->stamps + (size_t)(k + 1) * s->nt * 64 : nullptr;
+  }
+  int grid = 0;
+  ta.post = make_post_args(s, s->p.P, 0, 1, with_diag, &grid);
+  ta.post.wt = 1;
+  const double* pst[3] = {s->p.PA, s->p.PB, s->p.PA};
+  const double* pstk[3] = {s->p.PAK, s->p.PBK, s->p.PAK};
+  for (int k = 0; k < 3; ++k) { ta.Pst[k] = pst[k]; ta.PstK[k] = pstk[k]; }
+  ta.n_iters = n_iters;
+  ta.sync = s->p.sync;
+  ta.stamps = s->stamps;
+  return ta;
+}
+
+int launch_trial(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
+  const TrialArgs ta = make_trial_args(s, n_iters, with_diag);
+  // the barrier counts arrivals from zero in every launch (the give-up word is sticky: ldc_solver_status)
+  HIP_TRY(hipMemsetAsync(s->p.sync, 0, sizeof(uint32_t) * LDC_SYNC_GIVEUP, st));
+  const dim3 grid(s->nt), block(kStageThreads);
+  if (s->p.stage_pressure) hipLaunchKernelGGL((trial_kernel<true, false>), grid, block, kTrialLdsBytes, st, ta);
+  else if (with_diag) hipLaunchKernelGGL((trial_kernel<false, true>), grid, block, kTrialLdsBytes, st, ta);
+  else hipLaunchKernelGGL((trial_kernel<false, false>), grid, block, kTrialLdsBytes, st, ta);
+  return (int)hipGetLastError();
+}
+
 int build_graph(ldc_solver* s, int with_diag) {
   if (s->capture_stream == nullptr) HIP_TRY(hipStreamCreateWithFlags(&s->capture_stream, hipStreamNonBlocking));
   hipGraph_t g = nullptr;
@@ -1704,6 +2082,13 @@ int batch_build_graph(ldc_batch* b, int with_diag) {
 
 bool bad_ptr(const void* p) { return p == nullptr; }
 
+// a handle is used on the device it was created on (its kernels' attributes and its graphs live there)
+int on_own_device(const ldc_solver* s) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev != s->device) return LDC_E_STATE;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1716,6 +2101,7 @@ const char* ldc_error_string(int code) {
     case LDC_E_ARG: return "ldc: invalid argument (null pointer or inconsistent geometry)";
     case LDC_E_STATE: return "ldc: invalid solver handle/state";
     case LDC_E_NODEVICE: return "ldc: no gfx950 HIP device";
+    case LDC_E_SYNC: return "ldc: persistent trial kernel gave up a barrier wait (a work-group was not resident)";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "ldc: unknown error";
   }
 }
@@ -1750,9 +2136,22 @@ int ldc_solver_create(const ldc_problem* d, ldc_solver** out) {
                        d->UK, d->UTK, d->VK, d->VTK, d->PK, d->UAK, d->UATK, d->VAK, d->VATK,
                        d->UBK, d->UBTK, d->VBK, d->VBTK, d->T1TK, d->T2TK, d->WK, d->WTK};
   for (const void* q : req) if (bad_ptr(q)) return LDC_E_ARG;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  { const int e = enable_stage_lds_all<false>(); if (e) return e; }
+  int n_cus = 0;
+  HIP_TRY(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev));
+  if (d->sync != nullptr) {
+    if ((reinterpret_cast<uintptr_t>(d->sync) & 255) != 0) return LDC_E_ARG;
+    const int e = enable_trial_lds();
+    if (e) return e;
+  }
   ldc_solver* s = new (std::nothrow) ldc_solver;
   if (!s) return LDC_E_STATE;
   s->p = *d;
+  s->device = dev;
+  s->n_cus = n_cus;
+  s->persist_mode = -1;
   s->nt = d->T * d->T;
   s->n_edge_blocks = d->tail ? (2 * d->M - 1 + kWaves - 1) / kWaves : 0;
   s->n_pedge_blocks = d->tail ? (d->M + kWaves - 1) / kWaves : 0;
@@ -1781,6 +2180,22 @@ int ldc_solver_set_graph_iters(ldc_solver* s, int n) {
   return 0;
 }
 
+int ldc_solver_set_persistent(ldc_solver* s, int mode) {
+  if (!s) return LDC_E_STATE;
+  if (mode < -1 || mode > 1) return LDC_E_ARG;
+  if (mode == 1 && (s->p.sync == nullptr || s->nt > s->n_cus)) return LDC_E_ARG;
+  s->persist_mode = mode;
+  return 0;
+}
+
+int ldc_solver_status(ldc_solver* s) {
+  if (!s) return LDC_E_STATE;
+  if (s->p.sync == nullptr) return 0;
+  uint32_t flag = 0;
+  HIP_TRY(hipMemcpy(&flag, s->p.sync + LDC_SYNC_GIVEUP, sizeof(flag), hipMemcpyDeviceToHost));
+  return flag ? LDC_E_SYNC : 0;
+}
+
 int ldc_debug_ablate(ldc_solver* s, int mask) {
   if (!s) return LDC_E_STATE;
   s->ablate = mask;
@@ -1795,6 +2210,7 @@ int ldc_debug_stamps(ldc_solver* s, double* buf) {
 
 int ldc_stage(ldc_solver* s, int k, void* stream) {
   if (!s) return LDC_E_STATE;
+  { const int e = on_own_device(s); if (e) return e; }
   const int diag = (k & 16) ? 1 : 0;     // bit 4: the variant that also carries the fused diagnostics
   k &= 15;
   if (k < 0 || k > 3) return LDC_E_ARG;
@@ -1849,8 +2265,14 @@ int ldc_prime(ldc_solver* s, void* stream) {
 int ldc_solver_enqueue(ldc_solver* s, int n_iters, int with_diag, void* stream) {
   if (!s) return LDC_E_STATE;
   if (n_iters < 0) return LDC_E_ARG;
+  { const int e = on_own_device(s); if (e) return e; }
   with_diag = with_diag ? 1 : 0;
   hipStream_t st = as_stream(stream);
+  if (n_iters > 0 && use_persistent(s)) {
+    const int e = launch_trial(s, n_iters, with_diag, st);
+    if (e) return e;
+    return with_diag ? launch_closing_diagnostics(s, st) : 0;
+  }
   int left = n_iters;
   if (left >= s->iters_per_graph) {
     if (!s->graph[with_diag]) { int e = build_graph(s, with_diag); if (e) return e; }
@@ -1874,8 +2296,13 @@ int ldc_batch_create(ldc_solver* const* solvers, int n_trials, void* workspace, 
   for (int q = 0; q < n_trials; ++q) {
     const ldc_solver* t = solvers[q];
     if (!t) return LDC_E_STATE;
+    // one geometry, one tiling and one device for all: every launch takes its grid from solver 0
     if (t->p.M != s0->p.M || t->p.LD != s0->p.LD || t->p.stage_pressure != s0->p.stage_pressure) return LDC_E_ARG;
+    if (t->p.T != s0->p.T || t->p.tail != s0->p.tail || t->nt != s0->nt || t->n_edge_blocks != s0->n_edge_blocks ||
+        t->n_pedge_blocks != s0->n_pedge_blocks || t->device != s0->device)
+      return LDC_E_ARG;
   }
+  { int e = on_own_device(s0); if (e) return e; if ((e = enable_stage_lds_all<true>()) != 0) return e; }
   ldc_batch* b = new (std::nothrow) ldc_batch;
   if (!b) return LDC_E_STATE;
   b->B = n_trials;
@@ -1947,6 +2374,7 @@ int ldc_batch_destroy(ldc_batch* b) {
 int ldc_batch_enqueue(ldc_batch* b, int n_iters, int with_diag, void* stream) {
   if (!b) return LDC_E_STATE;
   if (n_iters < 0) return LDC_E_ARG;
+  { const int e = on_own_device(b->s[0]); if (e) return e; }
   with_diag = with_diag ? 1 : 0;
   hipStream_t st = as_stream(stream);
   int left = n_iters;
@@ -1969,6 +2397,7 @@ int ldc_pack(const double* src, double* dst, int LD, void* stream) {
 
 int ldc_residual_debug(ldc_solver* s, int which, double* const out[11], void* stream) {
   if (!s || !out) return LDC_E_ARG;
+  { const int e = on_own_device(s); if (e) return e; }
   for (int q = 0; q < 11; ++q) if (!out[q]) return LDC_E_ARG;
   if (which < 0 || which > 2) return LDC_E_ARG;
   hipStream_t st = as_stream(stream);

@@ -31,7 +31,7 @@ sys.path.insert(0, str(HERE / "src"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 from utilities.config import compose as C            # noqa: E402
-from utilities.sweep.farm import Dist, TPESampler, run_farm  # noqa: E402
+from utilities.sweep.farm import Dist, FarmError, TPESampler, run_farm  # noqa: E402
 
 log = logging.getLogger("main")
 
@@ -86,8 +86,20 @@ def run_solver(cfg: dict, out_dir: Path, device: str = None) -> dict:
         node["device"] = device
     solver = C.instantiate(node)
     t0 = time.perf_counter()
-    solver.solve()
-    rec = make_record(cfg, solver, out_dir, t0)
+    mlflow = _mlflow()
+    if mlflow is None:
+        solver.solve()
+        rec = make_record(cfg, solver, out_dir, t0)
+    else:
+        from utilities.tracking import sweep as T
+        if _TRACKER is None:
+            mlflow.set_tracking_uri(cfg.get("mlflow", {}).get("tracking_uri", "./mlruns"))
+            mlflow.set_experiment(T.experiment_name(cfg))
+        name = cfg["solver"]["name"]
+        n_display = cfg["N"] + 1 if str(name).startswith("spectral") else cfg["N"]
+        with T.open_child_run(mlflow, name, f"{name}_N{n_display}", _parent_of(cfg)):
+            solver.solve()                          # live metrics every 50 iterations go to this run
+            rec = make_record(cfg, solver, out_dir, t0)
     if hasattr(solver, "close"):
         solver.close()
     return rec
@@ -108,27 +120,57 @@ def run_batch(cfgs: list, out_dirs: list, device: str = None) -> list:
     batch = (BatchedFSGSolver if fsg else BatchedSGSolver)(nodes)
     batch.solve()
     recs = [make_record(cfg, s, d, t0) for cfg, s, d in zip(cfgs, batch.solvers, out_dirs)]
+    for r in recs:      # the batch's own wall time; a trial's wall_time_seconds is its share of it
+        r["solve_batch_seconds"], r["solve_batch_size"] = batch.batch_seconds, batch.batch_size
     batch.close()
     return recs
 
 
-def _mlflow_log(cfg, rec, solver):
-    """Mirror of the reference's tracking calls, active only when mlflow is installed."""
+_TRACKER = None        # utilities.tracking.sweep.SweepTracker of the running sweep (None: single run / no mlflow)
+
+
+def _mlflow():
     try:
         import mlflow
+        return mlflow
     except ImportError:
+        return None
+
+
+def _parent_of(cfg):
+    from utilities.tracking import sweep as T
+    if _TRACKER is not None:
+        return _TRACKER.parents.get(T.resolve_sweep_name(_TRACKER.base_sweep_name, cfg))
+    return None
+
+
+def _ts_batch(solver):
+    ts = getattr(solver, "time_series", None)
+    if ts is not None and hasattr(ts, "to_mlflow_batch"):
+        try:
+            return ts.to_mlflow_batch()
+        except Exception:                         # needs mlflow.entities; a stub without it is fine
+            return None
+    return None
+
+
+def _mlflow_log(cfg, rec, solver):
+    """Tracking of one finished trial (reference main.py:75-119), active only when mlflow is installed.  When a
+    run is already active (run_solver opened it before solve(), like the reference) the results go into it;
+    otherwise (batched trials) a child run is written after the fact.  In a sweep the run is nested under the
+    parent run of its ``sweep_name`` (utilities.tracking.sweep)."""
+    mlflow = _mlflow()
+    if mlflow is None:
         return
-    mlflow.set_tracking_uri(cfg.get("mlflow", {}).get("tracking_uri", "./mlruns"))
-    mlflow.set_experiment(cfg.get("experiment_name", "LDC-Dev"))
-    tags = {"solver": rec["solver"]}
-    parent = os.environ.get("MLFLOW_PARENT_RUN_ID")
-    if parent:
-        tags.update({"mlflow.parentRunId": parent, "parent_run_id": parent, "sweep": "child"})
-    with mlflow.start_run(run_name=rec["run_name"], tags=tags, nested=bool(parent)):
-        mlflow.log_params(rec["params"])
-        mlflow.log_metrics({k: v for k, v in rec["metrics"].items() if isinstance(v, (int, float))})
-        if rec["validation_errors"]:
-            mlflow.log_metrics(rec["validation_errors"])
+    from utilities.tracking import sweep as T
+    active = mlflow.active_run()
+    if active is not None:
+        T.log_results(mlflow, rec, active.info.run_id, _ts_batch(solver))
+        return
+    if _TRACKER is None:
+        mlflow.set_tracking_uri(cfg.get("mlflow", {}).get("tracking_uri", "./mlruns"))
+        mlflow.set_experiment(T.experiment_name(cfg))
+    T.log_child_run(mlflow, cfg, rec, parent_id=_parent_of(cfg), time_series_batch=_ts_batch(solver))
 
 
 def main(argv=None) -> float | None:
@@ -170,20 +212,27 @@ def main(argv=None) -> float | None:
         return C.resolve(cfg)
 
     def run_group(items, jobs, offset=0):
-        """items: [(index, trial)] owned by this rank with one group key; SG trials of equal N share launches."""
+        """items: [(index, trial)] owned by this rank with one group key.  Trials that can share their launches
+        -- same solver class, N, level hierarchy and diagnostics flag -- are advanced together; each keeps its
+        own Re / lid / tolerance / max_iterations (solvers.spectral.batched)."""
         cfgs = [job_cfg(jobs[i], offset + i) for i, _ in items]
-        out = []
-        targets = {c["solver"]["_target_"] for c in cfgs}
-        levels = {int(c["solver"].get("n_levels", 0)) for c in cfgs}
-        if targets in ({SG}, {FSG}) and len(levels) == 1 and len(cfgs) > 1 and max_batch > 1:
-            for lo in range(0, len(cfgs), max_batch):
-                part = cfgs[lo: lo + max_batch]
-                log.info("batch of %d trials at N=%s on %s", len(part), part[0]["N"], device or "cuda:0")
-                recs = run_batch(part, [root_dir / str(offset + i) for i, _ in items[lo: lo + max_batch]], device)
-                out.extend(recs)
-        else:
-            for (i, _), cfg in zip(items, cfgs):
-                out.append(run_solver(cfg, root_dir / str(offset + i), device=device))
+        out = [None] * len(cfgs)
+        share = {}
+        for q, c in enumerate(cfgs):
+            sv = c["solver"]
+            share.setdefault((sv["_target_"], int(c["N"]), int(sv.get("n_levels", 0)), bool(sv.get("diagnostics", True))),
+                             []).append(q)
+        for (target, _, _, _), members in share.items():
+            if target in (SG, FSG) and len(members) > 1 and max_batch > 1:
+                for lo in range(0, len(members), max_batch):
+                    part = members[lo: lo + max_batch]
+                    log.info("batch of %d trials at N=%s on %s", len(part), cfgs[part[0]]["N"], device or "cuda:0")
+                    recs = run_batch([cfgs[q] for q in part], [root_dir / str(offset + items[q][0]) for q in part], device)
+                    for q, r in zip(part, recs):
+                        out[q] = r
+            else:
+                for q in members:
+                    out[q] = run_solver(cfgs[q], root_dir / str(offset + items[q][0]), device=device)
         for (i, _), r in zip(items, out):
             r["overrides"] = {k: v for k, v in jobs[i]}
         return out
@@ -191,23 +240,57 @@ def main(argv=None) -> float | None:
     def key_of(jobs):
         return lambda t: (t.get("N"), str(dict(jobs[t["_job"]]).get("solver", "")))
 
+    def open_parents(jobs, offset=0):
+        """Job start of the reference's MLflowSweepCallback for every job of this round: rank 0 gets or creates
+        the parent run of each job's sweep_name, the other ranks adopt the map."""
+        if _TRACKER is None:
+            return
+        if dist.rank == 0:
+            for i, a in enumerate(jobs):
+                _TRACKER.parent_for(job_cfg(a, offset + i))
+        _TRACKER.adopt(dist.all_gather_object(_TRACKER.parents if dist.rank == 0 else {})[0])
+
+    global _TRACKER
+    _TRACKER = None
+    if multirun:
+        from utilities.tracking.sweep import SweepTracker
+        _TRACKER = SweepTracker.create(stamp_cfg)
+        if _TRACKER is not None:
+            _TRACKER.start(stamp_cfg, raw_sweep_name=base_cfg.get("sweep_name"))
+
     if not search:
         jobs = C.expand_grid(space)
+        open_parents(jobs)
         trials = [dict(a, N=dict(a).get("N", base_cfg.get("N", 32)), _job=i) for i, a in enumerate(jobs)]
-        recs = run_farm(trials, None, dist, run_group=lambda items: run_group(items, jobs), group_key=key_of(jobs))
+        failure = None
+        try:
+            recs = run_farm(trials, None, dist, run_group=lambda items: run_group(items, jobs), group_key=key_of(jobs))
+        except FarmError as exc:        # finished trials are kept and written out below, then the error surfaces
+            recs, failure = exc.records, exc
         objective = recs[0]["objective"] if len(recs) == 1 else None
     else:
         sw = stamp_cfg.get("hydra", {}).get("sweeper", {}) or {}
-        n_trials, n_jobs = int(sw.get("n_trials", 15)), max(int(sw.get("n_jobs", 1)), dist.world)
+        n_trials = int(sw.get("n_trials", 15))
+        # Candidates per round.  The reference asks Optuna for `n_jobs` trials at a time and runs them as
+        # `n_jobs` processes on one machine.  Here ONE GPU advances a whole batch of equal-N trials with the same
+        # launches at little more than the cost of one (an N=128 trial fills 64 of the 256 CUs), so every rank
+        # gets `trials_per_gpu` candidates per round (default: the experiment's n_jobs) and a round asks for
+        # trials_per_gpu x world of them.  With world = 1 this IS the reference's n_jobs; with more GPUs the
+        # sampler sees results in larger rounds, i.e. the TPE sequence depends on the world size (the reference's
+        # sampler seed is unset anyway: its sequence is not reproducible from run to run either).
+        per_gpu = int(os.environ.get("LDC_TRIALS_PER_GPU", sw.get("trials_per_gpu", sw.get("n_jobs", 1))))
+        n_jobs = max(1, per_gpu) * dist.world
         seed = int((sw.get("sampler") or {}).get("seed", 0))
         sampler = TPESampler(space, seed=seed)
-        recs, done = [], 0
+        recs, done, failure = [], 0, None
         while done < n_trials:
             batch = [sampler.ask() for _ in range(min(n_jobs, n_trials - done))]
             jobs = [list(b.items()) for b in batch]
+            open_parents(jobs, done)
             trials = [dict(b, N=b.get("N", base_cfg.get("N", 32)), _job=i) for i, b in enumerate(batch)]
+            # a failed trial is a failed trial (objective inf), like an exception inside an Optuna objective
             out = run_farm(trials, None, dist, run_group=lambda items: run_group(items, jobs, done),
-                           group_key=key_of(jobs))
+                           group_key=key_of(jobs), raise_on_error=False)
             for b, r in zip(batch, out):
                 sampler.tell(b, r["objective"] if isinstance(r["objective"], (int, float)) else math.inf)
             recs.extend(out)
@@ -215,12 +298,18 @@ def main(argv=None) -> float | None:
         best, val = sampler.best
         log.info("best trial: %s -> %s", best, val)
         objective = val
+    if _TRACKER is not None:
+        if dist.rank == 0:
+            _TRACKER.finish(stamp_cfg, recs, is_search=bool(search))
+        _TRACKER = None
     if dist.rank == 0 and (len(recs) > 1 or search):
         root_dir.mkdir(parents=True, exist_ok=True)
         (root_dir / "sweep_results.json").write_text(json.dumps(_jsonable(recs), indent=1))
         log.info("gathered %d trial records -> %s", len(recs), root_dir / "sweep_results.json")
     dist.barrier()
     dist.close()
+    if failure is not None:
+        raise failure
     return objective
 
 

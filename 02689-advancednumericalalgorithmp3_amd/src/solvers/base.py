@@ -74,8 +74,7 @@ class LidDrivenCavitySolver(ABC):
             if total_new == total:
                 raise RuntimeError("device loop made no progress")
             blocks.append(recs)
-            if log.isEnabledFor(logging.INFO) and len(recs):
-                log.info("Iteration %d: rel=%.6e", total_new - 1, recs[-1, REL])
+            self._live_log(recs, total, bool(done == 1))
             total = total_new
         wall = time.perf_counter() - t0
         log.info("Solver finished in %.2f seconds.", wall)
@@ -84,6 +83,50 @@ class LidDrivenCavitySolver(ABC):
         self.history = hist
         # the reference keeps history only after the first 10 iterations (base.py:264)
         self._store_results(hist[WARMUP_ITERATIONS:], total, done == 1, wall)
+
+    def _live_log(self, recs: np.ndarray, first: int, converged: bool, every: int = 50):
+        """The reference's progress line and live MLflow metrics for every 50th iteration and the converged one
+        (base.py:288-309).  The iterations of a chunk have already happened on the device when the host sees
+        their records, so the same lines and metrics are emitted chunk by chunk; the metrics go out as ONE
+        ``log_batch`` per chunk (same keys and ``step`` values as the reference's per-iteration
+        ``log_metrics`` calls)."""
+        n = len(recs)
+        if n == 0:
+            return
+        idx = [k for k in range(n) if (first + k) % every == 0]
+        if converged and (not idx or idx[-1] != n - 1):
+            idx.append(n - 1)
+        if not idx:
+            return
+        if log.isEnabledFor(logging.INFO):
+            for k in idx:
+                log.info("Iteration %d: rel=%.6e, u_res=%.6e, v_res=%.6e", first + k, recs[k, REL], recs[k, RU], recs[k, RV])
+        try:
+            import mlflow
+        except ImportError:
+            return
+        run = mlflow.active_run()
+        if run is None:
+            return
+        try:
+            from mlflow.entities import Metric
+            now = int(time.time() * 1000)
+            with_diag = bool(getattr(self.params, "diagnostics", True))
+            batch = []
+            for k in idx:
+                i = first + k
+                live = {"rel_iter_residual": recs[k, REL], "u_residual": recs[k, RU], "v_residual": recs[k, RV],
+                        "continuity_residual": recs[k, RP]}
+                if i >= WARMUP_ITERATIONS:
+                    live["energy"] = recs[k, EN]
+                    if with_diag:
+                        live["enstrophy"] = recs[k, ZN]
+                batch.extend(Metric(key, float(val), now, i) for key, val in live.items())
+            client = mlflow.tracking.MlflowClient()
+            for lo in range(0, len(batch), 1000):            # MLflow's limit per log_batch call
+                client.log_batch(run.info.run_id, metrics=batch[lo: lo + 1000])
+        except Exception as exc:                              # tracking must never stop a solve
+            log.warning("live metrics not logged: %s", exc)
 
     @staticmethod
     def _downsample(values: list, limit: int):

@@ -67,9 +67,12 @@ class SpectralParameters(Parameters):
     graph_iters: int = 32          # iterations captured per hipGraph
     nan_guard: bool = False        # quirk Q6: the reference SG spins on NaN; True = exit early
     diagnostics: bool = True       # E/Z/P every iteration, as base.py:274-276 does
+    persistent: int = -1           # iteration loop: 1 = ONE persistent launch per chunk (work-groups keep their
+                                   # tile, counter barrier per stage), 0 = one launch per RK stage (hipGraph),
+                                   # -1 = persistent where it pays (T*T <= 64 tiles, i.e. N <= 128); same results
 
     def to_mlflow(self) -> dict:
-        skip = {"device", "check_every", "graph_iters", "nan_guard", "diagnostics"}
+        skip = {"device", "check_every", "graph_iters", "nan_guard", "diagnostics", "persistent"}
         return {k: _mlflow_scalar(v) for k, v in self.as_dict().items() if k not in skip}
 
 

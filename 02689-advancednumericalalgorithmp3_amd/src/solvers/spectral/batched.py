@@ -21,6 +21,8 @@ from ..base import WARMUP_ITERATIONS
 
 log = logging.getLogger(__name__)
 
+LATCH_CAPPED = 3      # ctrl[DONE] code set by the host when a trial of a batch reaches its own max_iterations
+
 
 class BatchedSGSolver:
     """``trials``: list of SGSolver keyword dicts with identical nx/ny (and device)."""
@@ -56,11 +58,13 @@ class BatchedSGSolver:
         lib = L.lib()
         B = len(self.solvers)
         nbytes = lib.ldc_batch_workspace_bytes(B)
-        self._ws = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.solvers[0].device)
+        dev = self.solvers[0].device
+        self._ws = torch.zeros(nbytes + 256, dtype=torch.uint8, device=dev)
         base = (self._ws.data_ptr() + 255) & ~255
         arr = (C.c_void_p * B)(*[s._handle for s in self.solvers])
         h = C.c_void_p()
-        L.check(lib.ldc_batch_create(arr, B, base, nbytes, C.byref(h)), "ldc_batch_create")
+        with torch.cuda.device(dev):
+            L.check(lib.ldc_batch_create(arr, B, base, nbytes, C.byref(h)), "ldc_batch_create")
         self._batch = h
         self._batch_keys = [s._handle_key for s in self.solvers]
 
@@ -76,24 +80,43 @@ class BatchedSGSolver:
         for s in self.solvers:
             s.close()
 
-    def run_to_tolerance(self, tolerances, max_iter: int, diagnostics: bool = False) -> list:
-        """Every solver from its present state until ITS latch fires (or max_iter); returns per-solver
-        (latch, iterations, records).  Used by ``solve`` and by the batched FSG levels."""
+    def run_to_tolerance(self, tolerances, max_iter, diagnostics: bool = False) -> list:
+        """Every solver from its present state until ITS latch fires or ITS cap is reached (``max_iter``: one
+        int for all, or one per solver); returns per-solver (latch, iterations, records).  A trial that hits its
+        cap is latched on the device with code 3 (LATCH_CAPPED): its work-groups leave every later launch at
+        entry, exactly like a converged trial's, and its history stops there -- the same outcome as the
+        reference's one-process-per-trial runs with different ``max_iterations``.  Used by ``solve`` and by the
+        batched FSG levels."""
+        import torch
+        n = len(self.solvers)
+        caps = [int(max_iter)] * n if np.isscalar(max_iter) else [int(c) for c in max_iter]
+        if len(caps) != n:
+            raise ValueError("one iteration cap per solver expected")
         self._ensure_batch(list(tolerances))
         for s in self.solvers:
             s.d["ctrl"].zero_()
             s._prime()
         cap = min(s.rec_cap for s in self.solvers)
-        chunk = max(1, min(int(self.solvers[0].params.check_every), cap))
+        chunk = max(1, min(min(int(s.params.check_every) for s in self.solvers), cap))
         blocks = [[] for _ in self.solvers]
-        state = [(0, 0)] * len(self.solvers)
+        state = [(0, 0)] * n
         it = 0
-        while it < max_iter and not all(d for d, _ in state):
-            k = 1 if any(s._edge_fix_pending for s in self.solvers) else min(chunk, max_iter - it)
+        while True:
+            live = [q for q in range(n) if not state[q][0]]
+            for q in live:
+                if it >= caps[q]:                                   # cap reached: latch it on the device
+                    self.solvers[q].d["ctrl"][L.CTRL_DONE] = LATCH_CAPPED
+                    state[q] = (LATCH_CAPPED, state[q][1])
+            live = [q for q in live if not state[q][0]]
+            if not live:
+                break
+            k = 1 if any(s._edge_fix_pending for s in self.solvers) else min(chunk, min(caps[q] for q in live) - it)
             for q, (rows, done, total) in enumerate(self._advance(k, diagnostics)):
-                blocks[q].append(rows)
-                state[q] = (done, total)
+                if state[q][0] != LATCH_CAPPED:
+                    blocks[q].append(rows)
+                    state[q] = (done, total)
             it += k
+        torch.cuda.synchronize(self.solvers[0].device)
         return [(d, t, np.concatenate(b, axis=0) if b else np.zeros((0, 8))) for (d, t), b in zip(state, blocks)]
 
     def __del__(self):
@@ -109,7 +132,7 @@ class BatchedSGSolver:
         dev = self.solvers[0].device
         starts = [int(s.d["ctrl"].cpu().numpy()[L.CTRL_ITER]) for s in self.solvers]
         with torch.cuda.device(dev):
-            L.check(L.lib().ldc_batch_enqueue(self._batch, int(n_iters), int(bool(diagnostics)), L.stream_ptr()),
+            L.check(L.lib().ldc_batch_enqueue(self._batch, int(n_iters), int(bool(diagnostics)), L.stream_ptr(dev)),
                     "ldc_batch_enqueue")
             torch.cuda.synchronize(dev)
         out = []
@@ -139,16 +162,26 @@ class BatchedSGSolver:
         return [np.concatenate(r, axis=0) for r in rows]
 
     def solve(self, max_iter: int = None):
-        """Every trial to its own tolerance (or max_iterations); fills each solver's metrics/fields."""
-        p0 = self.solvers[0].params
-        max_iter = p0.max_iterations if max_iter is None else max_iter
-        diag = bool(p0.diagnostics)
+        """Every trial to its own tolerance or its own ``max_iterations``; fills each solver's metrics/fields.
+
+        The trials share every launch, so only the batch has a wall time of its own (``self.batch_seconds``).
+        A trial's ``metrics.wall_time_seconds`` is its SHARE of it, in proportion to its iteration count (the
+        shares add up to the batch's wall time), so ``iterations / wall_time_seconds`` of any trial is the
+        batch's aggregate rate in trial-iterations per second, not B times too low."""
+        ps = [s.params for s in self.solvers]
+        if len({bool(p.diagnostics) for p in ps}) != 1:
+            raise ValueError("trials of one batch must agree on `diagnostics` (it selects the kernels of the "
+                             "shared launches); batch them separately")
+        caps = [p.max_iterations for p in ps] if max_iter is None else [max_iter] * len(ps)
+        diag = bool(ps[0].diagnostics)
         t0 = time.perf_counter()
-        out = self.run_to_tolerance([s.params.tolerance for s in self.solvers], max_iter, diag)
+        out = self.run_to_tolerance([p.tolerance for p in ps], caps, diag)
         wall = time.perf_counter() - t0
+        self.batch_seconds, self.batch_size = wall, len(self.solvers)
+        its_all = max(1, sum(total for _, total, _ in out))
         for s, (done, total, hist) in zip(self.solvers, out):
             s.history = hist
-            s._store_results(hist[WARMUP_ITERATIONS:], total, done == 1, wall)
+            s._store_results(hist[WARMUP_ITERATIONS:], total, done == 1, wall * total / its_all)
         log.info("batched solve of %d trials finished in %.2f s", len(self.solvers), wall)
         return [s.metrics for s in self.solvers]
 
@@ -198,9 +231,9 @@ class BatchedFSGSolver:
                     fines[q]._prolongate(ladders[q][idx - 1], lvl)
             tols = [fines[q].params.tolerance * fines[q].params.coarse_tolerance_factor ** (nlev - 1 - idx)
                     for q in alive]
-            cap = min(fines[q].params.max_iterations for q in alive) if max_iter is None else max_iter
+            caps = [fines[q].params.max_iterations if max_iter is None else max_iter for q in alive]
             batch = BatchedSGSolver.from_solvers(group)
-            out = batch.run_to_tolerance(tols, cap, diagnostics=False)
+            out = batch.run_to_tolerance(tols, caps, diagnostics=False)
             batch.close_batch()
             nxt = []
             for q, (done, its, _) in zip(alive, out):
@@ -212,8 +245,11 @@ class BatchedFSGSolver:
                      [o[1] for o in out])
             alive = nxt
         wall = time.perf_counter() - t0
+        self.batch_seconds, self.batch_size = wall, len(fines)
+        its_all = max(1, sum(total))
         for q, s in enumerate(fines):
             for lvl in ladders[q][:-1]:
                 lvl.close()
-            s._finish(s.params.tolerance, total[q], last[q] == 1 and q in alive, wall)
+            # wall-time share by iteration count, see BatchedSGSolver.solve
+            s._finish(s.params.tolerance, total[q], last[q] == 1 and q in alive, wall * total[q] / its_all)
         return [s.metrics for s in fines]

@@ -63,14 +63,13 @@ class FSGSolver(SGSolver):
         Pf = padded(prolongation_matrix(method, Mc, Mf))                 # (Mf, Mc)
         Pi = padded(prolongation_matrix(method, Mc - 2, Mf - 2))         # inner grids
         X, Y = fine.d["S0"], fine.d["S1"]
-        st = L.stream_ptr()
 
         def apply(P, src_T, n_out):
             """P src P^T for a coarse field given as its transpose (LD-padded); returns LD x LD."""
             # X[i][b] = sum_a P[i][a] src[a][b] = sum_a P[i][a] srcT[b][a]
-            L.check(L.lib().ldc_gemm_nt(P.data_ptr(), src_T.data_ptr(), X.data_ptr(), R, R, LD, 0, 0, None, None, st))
+            fine._abi("ldc_gemm_nt", P.data_ptr(), src_T.data_ptr(), X.data_ptr(), R, R, LD, 0, 0, None, None)
             # out[i][j] = sum_b X[i][b] P[j][b]
-            L.check(L.lib().ldc_gemm_nt(X.data_ptr(), P.data_ptr(), Y.data_ptr(), R, R, LD, 0, 0, None, None, st))
+            fine._abi("ldc_gemm_nt", X.data_ptr(), P.data_ptr(), Y.data_ptr(), R, R, LD, 0, 0, None, None)
             return Y[:n_out, :n_out].clone()
 
         uc = padded(coarse.d["UT"][:Mc, :Mc])

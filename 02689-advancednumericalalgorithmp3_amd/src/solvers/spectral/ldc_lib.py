@@ -14,6 +14,8 @@ _PKG = Path(__file__).resolve().parents[3]          # .../02689-advancednumerica
 LIB_PATH = Path(os.environ.get("LDC_HIP_LIB", _PKG / "lib" / "libldc_hip.so"))
 
 REC_LEN, CTRL_LEN, SCAL_LEN, NPART = 8, 8, 8, 12
+SYNC_LEN, SYNC_GIVEUP = 64, 32
+ABI_VERSION = 3
 REC_REL, REC_RU, REC_RV, REC_RP, REC_E, REC_Z, REC_P, REC_DT = range(8)
 CTRL_DONE, CTRL_ITER = 0, 1
 SCAL_DT, SCAL_UMAX, SCAL_VMAX = 0, 1, 2
@@ -41,7 +43,7 @@ class Problem(C.Structure):
             "T1TK", "T2TK", "WK", "WTK",
             "partials")]
         + [("partials_stride", C.c_int64)]
-        + [(n, _dp) for n in ("scal", "ctrl", "rec")]
+        + [(n, _dp) for n in ("scal", "ctrl", "rec", "sync")]
     )
 
 
@@ -72,6 +74,8 @@ def lib() -> C.CDLL:
     L.ldc_solver_create.argtypes = [C.POINTER(Problem), C.POINTER(_dp)]
     L.ldc_solver_destroy.argtypes = [_dp]
     L.ldc_solver_set_graph_iters.argtypes = [_dp, C.c_int]
+    L.ldc_solver_set_persistent.argtypes = [_dp, C.c_int]
+    L.ldc_solver_status.argtypes = [_dp]
     L.ldc_stage.argtypes = [_dp, C.c_int, _dp]
     L.ldc_pressure_transform.argtypes = [_dp, C.c_int, _dp]
     L.ldc_diagnostics.argtypes = [_dp, _dp]
@@ -104,7 +108,8 @@ def lib() -> C.CDLL:
 EXPORTS = (
     "ldc_version", "ldc_error_string", "ldc_device_check", "ldc_solver_create", "ldc_solver_destroy",
     "ldc_stage", "ldc_pressure_transform", "ldc_diagnostics", "ldc_finalize", "ldc_prime", "ldc_global_quantities",
-    "ldc_solver_enqueue", "ldc_solver_set_graph_iters", "ldc_residual_debug", "ldc_gemm_nt",
+    "ldc_solver_enqueue", "ldc_solver_set_graph_iters", "ldc_solver_set_persistent", "ldc_solver_status",
+    "ldc_residual_debug", "ldc_gemm_nt",
     "ldc_batch_workspace_bytes", "ldc_batch_create", "ldc_batch_destroy", "ldc_batch_enqueue",
     "ldc_poisson_fastdiag", "ldc_vortex_extrema", "ldc_mfma_selftest", "ldc_mfma_peak", "ldc_debug_ablate", "ldc_debug_stamps",
     "ldc_pack",
@@ -116,22 +121,26 @@ def check(code: int, what: str = "ldc call"):
         raise LdcError(f"{what} failed: {lib().ldc_error_string(code).decode()} (code {code})")
 
 
-def require_device() -> str:
-    """Fail loudly unless torch sees a GPU and the library agrees it is a gfx950."""
+def require_device(device=None) -> str:
+    """Fail loudly unless torch sees a GPU and the library agrees that ``device`` (default: the
+    current one) is a gfx950.  The library looks at the CURRENT HIP device, so the check runs with
+    ``device`` made current."""
     import torch
     if not torch.cuda.is_available():
         raise LdcError("no HIP device visible: the spectral solver runs on MI355X (gfx950) only, "
                        "there is no CPU fallback")
     buf = C.create_string_buffer(64)
-    rc = lib().ldc_device_check(buf, 64)
+    with torch.cuda.device(device):
+        rc = lib().ldc_device_check(buf, 64)
     if rc != 0:
         raise LdcError(f"device '{buf.value.decode()}' is not gfx950: {lib().ldc_error_string(rc).decode()}")
     return buf.value.decode()
 
 
-def stream_ptr() -> int:
+def stream_ptr(device=None) -> int:
+    """Raw hipStream_t of torch's current stream on ``device`` (default: the current device)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def ptr(t) -> int:

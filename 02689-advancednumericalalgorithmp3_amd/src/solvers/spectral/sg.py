@@ -131,8 +131,10 @@ class SGSolver(LidDrivenCavitySolver):
 
     def _alloc_device(self):
         import torch
-        L.require_device()
         dev = torch.device(self.params.device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        L.require_device(dev)
         self.device = dev
         LD, M = self.LD, self.M
         self._mats = torch.zeros((len(_MAT_NAMES), LD, LD), dtype=torch.float64, device=dev)
@@ -146,6 +148,8 @@ class SGSolver(LidDrivenCavitySolver):
         self.d["partials"] = torch.zeros(5 * self._part_stride, dtype=torch.float64, device=dev)
         self.d["scal"] = torch.zeros(L.SCAL_LEN, dtype=torch.float64, device=dev)
         self.d["ctrl"] = torch.zeros(L.CTRL_LEN, dtype=torch.int32, device=dev)
+        # barrier words of the persistent trial kernel (256-byte aligned: torch's allocator hands out 512-byte blocks)
+        self.d["sync"] = torch.zeros(L.SYNC_LEN, dtype=torch.int32, device=dev)
         self.rec_cap = max(1, int(self.params.check_every))
         self.d["rec"] = torch.zeros((self.rec_cap, L.REC_LEN), dtype=torch.float64, device=dev)
         self.d["ext_val"] = torch.zeros(8, dtype=torch.float64, device=dev)
@@ -169,12 +173,19 @@ class SGSolver(LidDrivenCavitySolver):
             pad = np.zeros(LD); pad[:M] = v
             self.d[name].copy_(torch.from_numpy(pad))
 
+    def _abi(self, fn: str, *args):
+        """One C-ABI launch with THIS solver's device current and on its current stream (always the
+        last argument): the library launches on, and sets per-device kernel attributes for, the
+        current HIP device, whatever device the caller happens to have selected."""
+        import torch
+        with torch.cuda.device(self.device):
+            L.check(getattr(L.lib(), fn)(*args, L.stream_ptr(self.device)), fn)
+
     def _pack(self, names):
         """Bring the packed twins of the named row-major arrays up to date (host-side edits only:
         the kernels keep both forms in step themselves)."""
         for n in names:
-            L.check(L.lib().ldc_pack(self.d[n].data_ptr(), self.d[n + "K"].data_ptr(), self.LD, L.stream_ptr()),
-                    "ldc_pack")
+            self._abi("ldc_pack", self.d[n].data_ptr(), self.d[n + "K"].data_ptr(), self.LD)
 
     # ------------------------------------------------------------------ state transfer
     def _download_full(self, name: str) -> np.ndarray:
@@ -265,15 +276,18 @@ class SGSolver(LidDrivenCavitySolver):
         return pr
 
     def _ensure_handle(self, tol: float):
-        key = (tol, self._stage_pressure, self._warmup, self._nan_exit)
+        key = (tol, self._stage_pressure, self._warmup, self._nan_exit, int(self.params.persistent))
         if self._handle is not None and self._handle_key == key:
             return
         self._handle_key = key
         self.close()
         h = C.c_void_p()
         pr = self._problem(tol)
-        L.check(L.lib().ldc_solver_create(C.byref(pr), C.byref(h)), "ldc_solver_create")
+        import torch
+        with torch.cuda.device(self.device):      # the handle belongs to the device that is current here
+            L.check(L.lib().ldc_solver_create(C.byref(pr), C.byref(h)), "ldc_solver_create")
         L.check(L.lib().ldc_solver_set_graph_iters(h, int(self.params.graph_iters)), "ldc_solver_set_graph_iters")
+        L.check(L.lib().ldc_solver_set_persistent(h, int(self.params.persistent)), "ldc_solver_set_persistent")
         self._handle, self._handle_tol = h, tol
 
     def close(self):
@@ -291,7 +305,7 @@ class SGSolver(LidDrivenCavitySolver):
 
     def _prime(self):
         if not self._primed:
-            L.check(L.lib().ldc_prime(self._handle, L.stream_ptr()), "ldc_prime")
+            self._abi("ldc_prime", self._handle)
             self._primed = True
 
     # ------------------------------------------------------------------ driver hooks
@@ -314,12 +328,13 @@ class SGSolver(LidDrivenCavitySolver):
                 return rows1, done1, end1
             rows2, done2, end2 = self._advance(n_iters - 1)
             return np.concatenate([rows1, rows2], axis=0), done2, end2
-        with torch.cuda.device(self.device):
-            L.check(L.lib().ldc_solver_enqueue(self._handle, n_iters, int(bool(self.params.diagnostics)),
-                                               L.stream_ptr()), "ldc_solver_enqueue")
-            torch.cuda.synchronize(self.device)
+        self._abi("ldc_solver_enqueue", self._handle, n_iters, int(bool(self.params.diagnostics)))
+        torch.cuda.synchronize(self.device)
         ctrl = self.d["ctrl"].cpu().numpy()
         end, done = int(ctrl[L.CTRL_ITER]), int(ctrl[L.CTRL_DONE])
+        if int(self.d["sync"][L.SYNC_GIVEUP]) != 0:
+            raise L.LdcError("persistent trial kernel gave up a barrier wait (a work-group was not resident); "
+                             "the state is undefined -- rerun with persistent=0")
         ring = self.d["rec"].cpu().numpy()
         rows = ring[np.arange(start, end) % self.rec_cap]
         if self._edge_fix_pending and end > start:
@@ -382,7 +397,7 @@ class SGSolver(LidDrivenCavitySolver):
         for t in outs:
             t.zero_()
         arr = (C.c_void_p * 11)(*[t.data_ptr() for t in outs])
-        L.check(L.lib().ldc_residual_debug(self._handle, which, arr, L.stream_ptr()), "ldc_residual_debug")
+        self._abi("ldc_residual_debug", self._handle, which, arr)
         torch.cuda.synchronize(self.device)
         M = self.M
         res = {}
@@ -396,7 +411,7 @@ class SGSolver(LidDrivenCavitySolver):
         import torch
         self._ensure_handle(self.params.tolerance if self._handle_tol is None else self._handle_tol)
         out = self.d["ext_val"]
-        L.check(L.lib().ldc_global_quantities(self._handle, out.data_ptr(), L.stream_ptr()), "ldc_global_quantities")
+        self._abi("ldc_global_quantities", self._handle, out.data_ptr())
         torch.cuda.synchronize(self.device)
         e, z, p = out[:3].cpu().numpy()
         return {"E": float(e), "Z": float(z), "P": float(p)}
@@ -405,7 +420,7 @@ class SGSolver(LidDrivenCavitySolver):
     def _compute_vorticity(self) -> np.ndarray:
         import torch
         self._ensure_handle(self.params.tolerance if self._handle_tol is None else self._handle_tol)
-        L.check(L.lib().ldc_diagnostics(self._handle, L.stream_ptr()), "ldc_diagnostics")
+        self._abi("ldc_diagnostics", self._handle)
         torch.cuda.synchronize(self.device)
         return self._download_full("W").ravel()
 
@@ -440,10 +455,10 @@ class SGSolver(LidDrivenCavitySolver):
         F, w0, w1, Psi = self.d["S0"], self.d["S1"], self.d["S2"], self.d["S3"]
         F.zero_()
         F[:Mi, :Mi] = -self.d["W"][1: M - 1, 1: M - 1]
-        L.check(L.lib().ldc_poisson_fastdiag(
-            Q[0].data_ptr(), Q[1].data_ptr(), Q[2].data_ptr(), Q[3].data_ptr(),
-            self.d["lamx"].data_ptr(), self.d["lamy"].data_ptr(), F.data_ptr(), w0.data_ptr(),
-            w1.data_ptr(), Psi.data_ptr(), Mi, self.LD, L.stream_ptr()), "ldc_poisson_fastdiag")
+        self._abi("ldc_poisson_fastdiag",
+                  Q[0].data_ptr(), Q[1].data_ptr(), Q[2].data_ptr(), Q[3].data_ptr(),
+                  self.d["lamx"].data_ptr(), self.d["lamy"].data_ptr(), F.data_ptr(), w0.data_ptr(),
+                  w1.data_ptr(), Psi.data_ptr(), Mi, self.LD)
         full = self.d["S4"]
         full.zero_()
         full[1: M - 1, 1: M - 1] = Psi[:Mi, :Mi]
@@ -453,10 +468,9 @@ class SGSolver(LidDrivenCavitySolver):
     def compute_vortex_metrics(self) -> dict:
         import torch
         self._compute_streamfunction()          # leaves psi in S4 and omega in W
-        L.check(L.lib().ldc_vortex_extrema(
-            self.d["S4"].data_ptr(), self.d["W"].data_ptr(), self.d["x"].data_ptr(), self.d["y"].data_ptr(),
-            self.M, self.LD, self.d["ext_val"].data_ptr(), self.d["ext_idx"].data_ptr(), L.stream_ptr()),
-            "ldc_vortex_extrema")
+        self._abi("ldc_vortex_extrema",
+                  self.d["S4"].data_ptr(), self.d["W"].data_ptr(), self.d["x"].data_ptr(), self.d["y"].data_ptr(),
+                  self.M, self.LD, self.d["ext_val"].data_ptr(), self.d["ext_idx"].data_ptr())
         torch.cuda.synchronize(self.device)
         val = self.d["ext_val"].cpu().numpy()
         idx = self.d["ext_idx"].cpu().numpy()

@@ -8,11 +8,15 @@ own GPU and only the small result records are gathered (``all_gather_object``).
 """
 from __future__ import annotations
 
+import logging
 import math
 import os
 import time
 
 import numpy as np
+
+
+log = logging.getLogger(__name__)
 
 
 def trial_cost(trial: dict) -> float:
@@ -77,13 +81,19 @@ class Dist:
             self._pg = None
 
 
-def run_farm(trials: list, run_trial, dist: Dist, cost=trial_cost, run_group=None, group_key=None) -> list:
+def run_farm(trials: list, run_trial, dist: Dist, cost=trial_cost, run_group=None, group_key=None,
+             raise_on_error: bool = True) -> list:
     """Run every trial exactly once; returns the list of result records on every rank, in trial order.
 
     ``run_trial(trial, index)`` -> JSON-able dict.  Scheduling is static LPT computed identically on all
     ranks, so no work needs to be communicated.  With ``run_group`` the trials a rank owns are grouped by
     ``group_key(trial)`` and handed over together -- ``run_group([(index, trial), ...]) -> [record, ...]`` --
-    so that equal-N trials can share every kernel launch on that GPU (solvers.spectral.batched)."""
+    so that equal-N trials can share every kernel launch on that GPU (solvers.spectral.batched).
+
+    A trial (or group) that raises does not take the sweep down with it: its records become
+    ``{"error": repr(exc), "objective": inf}``, every rank still reaches the gather, and afterwards
+    ``FarmError`` (carrying all records) is raised on all ranks alike unless ``raise_on_error`` is false --
+    like the reference's joblib / Optuna launchers, which surface the exception and keep finished trials."""
     owner = assign_lpt([cost(t) for t in trials], dist.world)
     mine = {}
     my = [(idx, t) for idx, t in enumerate(trials) if owner[idx] == dist.rank]
@@ -96,16 +106,36 @@ def run_farm(trials: list, run_trial, dist: Dist, cost=trial_cost, run_group=Non
         groups = list(by_key.values())
     for grp in groups:
         t0 = time.perf_counter()
-        recs = run_group(grp) if run_group is not None else [run_trial(grp[0][1], grp[0][0])]
+        try:
+            recs = run_group(grp) if run_group is not None else [run_trial(grp[0][1], grp[0][0])]
+        except Exception as exc:          # keep going: every rank must reach the gather below
+            log.exception("trial group %s failed on rank %d", [i for i, _ in grp], dist.rank)
+            recs = [dict(error=repr(exc), objective=math.inf) for _ in grp]
         dt = time.perf_counter() - t0
         for (idx, _), rec in zip(grp, recs):
             rec = dict(rec)
-            rec.update(trial_index=idx, rank=dist.rank, trial_seconds=dt, batch_size=len(grp))
+            # the trials of a group share every launch: the group has ONE wall time (batch_seconds);
+            # trial_seconds is the amortised time per trial
+            rec.update(trial_index=idx, rank=dist.rank, batch_seconds=dt, batch_size=len(grp),
+                       trial_seconds=dt / len(grp))
             mine[idx] = rec
     merged = {}
     for part in dist.all_gather_object(mine):
         merged.update(part)
-    return [merged[i] for i in range(len(trials))]
+    out = [merged[i] for i in range(len(trials))]
+    failed = [r["trial_index"] for r in out if "error" in r]
+    if failed and raise_on_error:
+        raise FarmError(f"trials {failed} failed: " + "; ".join(out[i]["error"] for i in failed[:3]), out)
+    return out
+
+
+class FarmError(RuntimeError):
+    """Raised on EVERY rank after the gather when any trial failed; ``records`` holds all trial records
+    (finished ones intact, failed ones as ``{"error": ..., "objective": inf}``)."""
+
+    def __init__(self, msg, records):
+        super().__init__(msg)
+        self.records = records
 
 
 class TPESampler:
@@ -172,12 +202,14 @@ class TPESampler:
         return best
 
     def tell(self, trial: dict, value: float):
+        """A non-finite objective (a diverged trial gives NaN) counts as a failed trial: +inf, like Optuna."""
+        v = math.inf if value is None else float(value)
         self.trials.append(dict(trial))
-        self.values.append(float(value) if value is not None else math.inf)
+        self.values.append(v if math.isfinite(v) else math.inf)
 
     @property
     def best(self):
         if not self.values:
             return None, math.inf
-        i = int(np.argmin(self.values))
+        i = int(np.argmin(self.values))          # values are finite or +inf (tell): never NaN
         return self.trials[i], self.values[i]

@@ -12,7 +12,12 @@
  *  - every pointer in `ldc_problem` is a DEVICE pointer into caller-owned memory
  *    (torch.float64 / torch.int32 tensors on the host side); the library allocates no
  *    device memory and keeps no globals.  A solver handle owns only its captured
- *    hipGraph executables.
+ *    hipGraph executables.  It belongs to the HIP device that is current when it is created
+ *    (dynamic-LDS attributes of its kernels are set there); using it with another device
+ *    current returns LDC_E_STATE.
+ *  - one grid per solve: the same number of nodes M on both axes (the reference builds
+ *    independent x / y grids, sg.py:103-119, but every configuration it ships sets nx = ny = N;
+ *    the plugin class raises NotImplementedError for nx != ny).  Lx != Ly is supported.
  *  - all 2-D arrays are row-major LD x LD doubles, zero padded, element [ix][iy]
  *    (reference sg.py:108, indexing="ij"); LD is a multiple of 16 and >= 16*T + 16.
  *  - "transposed copy" XT means XT[iy][ix] = X[ix][iy]; the kernels keep both so that
@@ -38,11 +43,12 @@
 extern "C" {
 #endif
 
-#define LDC_ABI_VERSION 2
+#define LDC_ABI_VERSION 3
 
 #define LDC_E_ARG      (-1)  /* null pointer / inconsistent geometry */
 #define LDC_E_STATE    (-2)  /* handle not valid for the call */
 #define LDC_E_NODEVICE (-3)  /* no HIP device / wrong architecture */
+#define LDC_E_SYNC     (-4)  /* persistent trial kernel: a grid-barrier wait was given up (ldc_solver_status) */
 
 /* slots of one history record written per iteration (ldc_problem.rec) */
 enum {
@@ -59,7 +65,8 @@ enum {
 
 /* ctrl[] (int32) slots */
 enum {
-  LDC_CTRL_DONE      = 0, /* latch: 1 converged, 2 non-finite; later launches are no-ops */
+  LDC_CTRL_DONE      = 0, /* latch: 1 converged, 2 non-finite, 3 set by the HOST (a batched trial reached its own
+                             iteration cap); any non-zero value turns later launches into no-ops */
   LDC_CTRL_ITER      = 1, /* iterations finalized (records written)                     */
   LDC_CTRL_STEP      = 2, /* stage-4 state updates completed                            */
   LDC_CTRL_FLUSHED   = 3, /* records whose Z/P slots have been folded                   */
@@ -77,6 +84,13 @@ enum {
 };
 
 #define LDC_NPART 12   /* doubles per work-group in `partials` */
+
+/* sync[] (uint32) slots of the persistent trial kernel; each on a 128-byte line of its own */
+enum {
+  LDC_SYNC_ARRIVE = 0,   /* arrival counter of the barrier among the trial's work-groups          */
+  LDC_SYNC_GIVEUP = 32,  /* set to 1 by a work-group whose bounded wait on the counter ran out    */
+  LDC_SYNC_LEN    = 64
+};
 
 typedef struct ldc_problem {
   /* geometry */
@@ -127,6 +141,8 @@ typedef struct ldc_problem {
   double  *scal;      /* LDC_SCAL_LEN doubles                                           */
   int32_t *ctrl;      /* LDC_CTRL_LEN int32                                             */
   double  *rec;       /* rec_cap * LDC_REC_LEN doubles, ring indexed by iteration       */
+  uint32_t *sync;     /* LDC_SYNC_LEN uint32 (256-byte aligned) for the persistent trial kernel, or NULL:
+                         the launch-per-stage path is then the only one                  */
 } ldc_problem;
 
 typedef struct ldc_solver ldc_solver;   /* opaque */
@@ -167,6 +183,16 @@ int ldc_prime(ldc_solver *s, void *stream);
 int ldc_solver_enqueue(ldc_solver *s, int n_iters, int with_diagnostics, void *stream);
 /* iterations captured per graph (default 32); must be set before the first enqueue      */
 int ldc_solver_set_graph_iters(ldc_solver *s, int iters_per_graph);
+/* How ldc_solver_enqueue runs the loop.  mode 0: one launch per RK stage (hipGraph replay); 1: the persistent   */
+/* trial kernel -- ALL n_iters iterations in ONE launch of T*T work-groups that keep their tile and meet at a    */
+/* counter barrier per stage (needs desc->sync and T*T <= CUs of the device, else LDC_E_ARG); -1 (default):      */
+/* persistent when it is available and T*T <= LDC_PERSIST_AUTO_TILES.  Same arithmetic either way: records and   */
+/* fields are bit-identical.                                                                                     */
+#define LDC_PERSIST_AUTO_TILES 0
+int ldc_solver_set_persistent(ldc_solver *s, int mode);
+/* 0, or LDC_E_SYNC when a persistent launch of this handle gave up a barrier wait (a work-group was not         */
+/* resident): the state is then undefined.  Reads desc->sync on the host: SYNCHRONISES the device.               */
+int ldc_solver_status(ldc_solver *s);
 
 /* batched trials (the sweep axis of the reference on ONE GPU): n_trials solver handles of      */
 /* identical geometry (M, LD, mode) advanced by the same launches, blockIdx.y = trial; each     */

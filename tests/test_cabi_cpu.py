@@ -25,12 +25,12 @@ def test_header_and_exports_agree(lib):
     L = lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ldc_version() == 2
+    assert L.ldc_version() == lib.ABI_VERSION == 3
 
 
 def test_struct_size_matches_header(lib):
-    # 4 int32 + 7 double + 4 int32 + (37 + 27 packed twins) ptr + int64 + 3 ptr
-    assert C.sizeof(lib.Problem) == 16 + 56 + 16 + (37 + 27) * 8 + 8 + 24
+    # 4 int32 + 7 double + 4 int32 + (37 + 27 packed twins) ptr + int64 + 4 ptr (scal, ctrl, rec, sync)
+    assert C.sizeof(lib.Problem) == 16 + 56 + 16 + (37 + 27) * 8 + 8 + 32
 
 
 def test_argument_validation_needs_no_device(lib):
@@ -41,6 +41,8 @@ def test_argument_validation_needs_no_device(lib):
     assert L.ldc_solver_create(None, C.byref(h)) == -1
     assert L.ldc_stage(None, 0, None) == -2                             # LDC_E_STATE
     assert L.ldc_solver_enqueue(None, 1, 1, None) == -2
+    assert L.ldc_solver_set_persistent(None, 1) == -2 and L.ldc_solver_status(None) == -2
+    assert b"barrier" in L.ldc_error_string(-4)                          # LDC_E_SYNC
     assert L.ldc_gemm_nt(None, None, None, 1, 1, 16, 0, 0, None, None, None) == -1
     assert b"invalid argument" in L.ldc_error_string(-1)
 

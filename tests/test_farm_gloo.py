@@ -61,6 +61,19 @@ def test_two_rank_gloo_farm(tmp_path):
     r0, r1 = (json.loads((tmp_path / f"rank{k}.json").read_text()) for k in (0, 1))
     assert r0 == r1 and r0["n"] == 12
     assert res["best"] <= min(h for hh in res["hist"][:2] for h in hh)
+    # search round of the launcher: 4 candidates per GPU x 2 ranks, each rank ran ONE group of 4 equal-N trials
+    g0, g1 = (json.loads((tmp_path / f"groups{k}.json").read_text()) for k in (0, 1))
+    assert len(g0["groups"]) == 1 and len(g1["groups"]) == 1
+    assert len(g0["groups"][0]) == 4 and len(g1["groups"][0]) == 4
+    assert sorted(g0["groups"][0] + g1["groups"][0]) == list(range(8))
+    assert [r["batch_size"] for r in res["round_recs"]] == [4] * 8
+    assert {r["rank"] for r in res["round_recs"]} == {0, 1}
+    # the failing trial: FarmError on BOTH ranks, the three finished trials kept
+    for g in (g0, g1):
+        fe = g["farm_error"]
+        assert fe is not None and "boom" in fe["msg"]
+        assert fe["errors"] == [False, True, False, False]
+        assert fe["kept"][0] == 0.0 and fe["kept"][2] == 2.0 and fe["kept"][3] == 3.0
 
 
 def test_farm_groups_equal_n_trials_for_batching():
@@ -75,3 +88,39 @@ def test_farm_groups_equal_n_trials_for_batching():
     out = run_farm(trials, None, d, run_group=run_group, group_key=lambda t: t["N"])
     assert seen == [[0, 1, 2], [3]]
     assert [r["v"] for r in out] == [1, 2, 3, 9] and [r["batch_size"] for r in out] == [3, 3, 3, 1]
+
+
+def test_tpe_treats_a_nan_objective_as_a_failed_trial():
+    """A diverged trial has psi_min = NaN, so its botella_vortex objective is NaN; it must neither be
+    reported as the optimum nor poison the Parzen windows."""
+    import math
+    from utilities.config.compose import Interval
+    from utilities.sweep.farm import TPESampler
+    s = TPESampler({"a": Interval(0.0, 1.0)}, seed=0)
+    s.tell({"a": 0.1}, 1.0)
+    s.tell({"a": 0.2}, float("nan"))
+    s.tell({"a": 0.3}, 0.5)
+    s.tell({"a": 0.4}, None)
+    best, val = s.best
+    assert best == {"a": 0.3} and val == 0.5
+    assert s.values[1] == math.inf and s.values[3] == math.inf
+    only_bad = TPESampler({"a": Interval(0.0, 1.0)}, seed=0)
+    only_bad.tell({"a": 0.2}, float("nan"))
+    assert only_bad.best[1] == math.inf
+    assert 0.0 <= only_bad.ask()["a"] <= 1.0
+
+
+def test_farm_error_keeps_finished_trials_single_process():
+    from utilities.sweep.farm import FarmError
+
+    def run(t, i):
+        if t["N"] == 8:
+            raise ValueError("bad config")
+        return dict(v=t["N"])
+
+    with pytest.raises(FarmError) as ei:
+        run_farm([dict(N=4), dict(N=8), dict(N=16)], run, Dist())
+    recs = ei.value.records
+    assert recs[0]["v"] == 4 and recs[2]["v"] == 16 and "bad config" in recs[1]["error"]
+    out = run_farm([dict(N=4), dict(N=8)], run, Dist(), raise_on_error=False)
+    assert out[0]["v"] == 4 and out[1]["objective"] == float("inf")

@@ -1,0 +1,34 @@
+"""Persistent trial kernel vs launch-per-stage path: microseconds per iteration by N (development aid).
+    python tools/ab_persist.py [N ...]        env: AB_DIAG=0/1 (default 1), AB_ITERS"""
+import os
+import sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "02689-advancednumericalalgorithmp3_amd", "src"))
+import torch
+from solvers.spectral import ldc_lib as L
+from solvers.spectral.sg import SGSolver
+
+sizes = [int(a) for a in sys.argv[1:]] or [32, 64, 96, 128]
+diag = bool(int(os.environ.get("AB_DIAG", "1")))
+iters = int(os.environ.get("AB_ITERS", "2048"))
+for N in sizes:
+    row = []
+    for mode in (1, 0):
+        try:
+            s = SGSolver(name="spectral", Re=1000.0, nx=N, ny=N, basis_type="chebyshev", CFL=1.5, tolerance=0.0,
+                         max_iterations=10**9, check_every=4096, graph_iters=32, persistent=mode)
+            s.run_iterations(256, diagnostics=diag)
+            best = 1e30
+            for rep in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(); e0.record()
+                L.check(L.lib().ldc_solver_enqueue(s._handle, iters, int(diag), L.stream_ptr()))
+                e1.record(); torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) * 1e3 / iters)
+            assert int(s.d["sync"][L.SYNC_GIVEUP]) == 0, "a barrier wait was given up"
+            row.append(best)
+            s.close()
+        except Exception as exc:          # e.g. persistent not available at this size
+            row.append(float("nan"))
+            print(f"N={N} mode={mode}: {exc}", flush=True)
+    print(f"N={N:4d} diag={int(diag)}  persistent {row[0]:8.2f} us/iter   launches {row[1]:8.2f} us/iter   "
+          f"ratio {row[1] / row[0]:.2f}x", flush=True)
