@@ -147,10 +147,34 @@ __device__ __forceinline__ double wave_max(double x) {
   x = fmax(x, dpp_move<0x140>(x));
   return fmax(fmax(lane_value(x, 0), lane_value(x, 16)), fmax(lane_value(x, 32), lane_value(x, 48)));
 }
+// ---- node arithmetic, shared by every kernel that evaluates a stage ---------------------------------------------
+// Explicit FMAs with contraction switched off: which multiply of `a*b + c*d` hipcc fuses depends on the code around
+// the expression, and the launch-per-stage kernels and the tile-resident kernel must round identically (their
+// trajectories are compared bit for bit).  Every multiply-add of the epilogues goes through these.
+#pragma clang fp contract(off)
+__device__ __forceinline__ double nm_madd(double a, double b, double c) { return fma(a, b, c); }       // a b + c
+__device__ __forceinline__ double nm_sq2(double a, double b) { return fma(b, b, a * a); }              // a^2 + b^2
+// rank-1 completion for k = M-1 of the six contractions at a node (tail layout)
+__device__ __forceinline__ void nm_tail(double& ux, double& vx, double& uy, double& vy, double& lu, double& lv,
+                                        double dxl, double d2xl, double dyl, double d2yl, double ue, double ve,
+                                        double un_, double vn_) {
+  ux = fma(dxl, ue, ux); vx = fma(dxl, ve, vx);
+  uy = fma(un_, dyl, uy); vy = fma(vn_, dyl, vy);
+  lu += fma(d2xl, ue, un_ * d2yl);
+  lv += fma(d2xl, ve, vn_ * d2yl);
+}
+// -(u dq/dx + v dq/dy) - dp/dq + nu lap q      (sg.py:331-338)
+__device__ __forceinline__ double nm_momentum(double uin, double vin, double qx, double qy, double gp, double nu,
+                                              double lap) {
+  return fma(nu, lap, -fma(vin, qy, uin * qx) - gp);
+}
+__device__ __forceinline__ double nm_continuity(double beta2, double ux, double vy) { return -beta2 * (ux + vy); }
+#pragma clang fp contract(fast)
+
 // wave-cooperative dot product of two contiguous rows (fixed order => deterministic)
 __device__ __forceinline__ double dot_rows(const double* a, const double* b, int n, int lane) {
   double s = 0.0;
-  for (int k = lane; k < n; k += 64) s += a[k] * b[k];
+  for (int k = lane; k < n; k += 64) s = nm_madd(a[k], b[k], s);
   return wave_sum(s);
 }
 
@@ -389,7 +413,10 @@ struct EdgeAcc {
 //      2 = ONE contraction in slot 0, the one the vorticity needs from this role (DIAG 1):
 //          role 0: A0.B1 = Dx . VT (dv/dx)      role 1: A0.B0 = U . Dy (du/dy)
 // GP : the fifth contraction (grad p, or grad omega by o.x4)
-template <int VEL, bool GP>
+// SA2 / SB2: the LDS slots that hold the rows of index M-1 of the fifth contraction's operands (the launch kernels
+// stage them in slots 2 and 5; the tile-resident kernel keeps the constant rows in place and uses separate slots
+// for the rows that change)
+template <int VEL, bool GP, int SA2 = 2, int SB2 = 5>
 __device__ __forceinline__ void edge_group(EdgeAcc& e, const RoleFrags& f, const ExtraFrags& x, const RoleOps& o,
                                            const double* erow, int n, int lane, bool rowE, bool colE, bool cornE) {
   // erow: this WAVE's pieces of the six rows of index M-1 (slots A0 A1 A2 B0 B1 B2) x its (at most four)
@@ -404,12 +431,12 @@ __device__ __forceinline__ void edge_group(EdgeAcc& e, const RoleFrags& f, const
   if (rowE || cornE) {
     if (need_a0_row) ar0 = row_of(0);
     if (VEL == 1) ar1 = row_of(1);
-    if (GP) xr = (o.x4 == 1) ? ar0 : row_of(2);
+    if (GP) xr = (o.x4 == 1) ? ar0 : row_of(SA2);
   }
   if (colE || cornE) {
     if (need_b0_col) bc0 = row_of(3);
     if (need_b1_col) bc1 = row_of(4);
-    if (GP) yc = (o.x4 == 2) ? bc0 : row_of(5);
+    if (GP) yc = (o.x4 == 2) ? bc0 : row_of(SB2);
   }
   if (rowE) {
     if (VEL == 1) {
@@ -487,13 +514,10 @@ struct StageLds {
 //        forms anyway, its enstrophy partial sums and the omega / omega^T arrays; 2 (stage 2) the two
 //        contractions Dx.omega, omega.Dy^T and the palinstrophy partial sums.  Both belong to the record
 //        of iteration n and are folded by the finalize block of the next post launch.
-// PERSIST: the body runs as one PHASE of the persistent trial kernel (trial_kernel below): `bx` / `nblk` stand in for
-//        blockIdx.x / gridDim.x, the latch, the step counter and dt come from the kernel's own control block
-//        (p_latched, p_step0, p_dt) instead of ctrl / scal, every load of state is a coherent (sc1) load and every
-//        store of it write-through, and no control word is written (the kernel keeps them in LDS until it ends).
-template <bool GPV, bool LAST, bool DUMP, bool BATCH, int DIAG, bool PERSIST>
-__device__ __forceinline__ void stage_body(const StageArgs a, const int bx, const int nblk, double* lds,
-                                           const int p_latched, const int p_step0, const double p_dt) {
+// (the body is a function of its own so that `a` is a by-value copy the compiler can keep in scalar registers; the
+//  tile-resident form of the same stage for the persistent trial kernel is tile_stage below)
+template <bool GPV, bool LAST, bool DUMP, bool BATCH, int DIAG>
+__device__ __forceinline__ void stage_body(const StageArgs a, const int bx, const int nblk, double* lds) {
   constexpr bool GP = GPV || (DIAG == 2);      // "has a fifth contraction" (grad p or grad omega)
   static_assert(!(GPV && DIAG == 2), "stage 2 of SG carries no pressure contraction");
   constexpr int VEL = (LAST || DUMP) ? 1 : (DIAG == 1 ? 2 : 0);   // what the nodes of index M-1 need here
@@ -550,24 +574,24 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
     const double* s01 = sl ? o.row[1] : o.row[0];
     const double* s23 = sl ? o.row[3] : o.row[2];
     const double* s45 = sl ? o.row[5] : o.row[4];
-    if (live && needA && s01 != nullptr) dma16<PERSIST>(s01 + off, erow);
-    if (live && (sl ? needB : needA) && s23 != nullptr) dma16<PERSIST>(s23 + off, erow + 128);
-    if (live && needB && s45 != nullptr) dma16<PERSIST>(s45 + off, erow + 256);
+    if (live && needA && s01 != nullptr) dma16<false>(s01 + off, erow);
+    if (live && (sl ? needB : needA) && s23 != nullptr) dma16<false>(s23 + off, erow + 128);
+    if (live && needB && s45 != nullptr) dma16<false>(s45 + off, erow + 256);
   }
 
   // ---- first fragments in flight before anything else ------------------------------------
   RoleFrags fa, fb;
   ExtraFrags fx;
-  load_role<PERSIST>(fa, o, NB, I, J, ng > 0 ? gk(0) : 0, lane);
+  load_role<false>(fa, o, NB, I, J, ng > 0 ? gk(0) : 0, lane);
 
   // The latch, the step counter and dt are only READ here (scalar loads, nobody waits for them yet); the
   // latch is acted upon after the K loop.  An early `return` at this point made the compiler sink the
   // fragment loads below it: kernel arguments -> latch -> operand pointers -> fragments became four cold
   // misses in a row (~1.4 us before the first MFMA).  A latched launch now runs its K loop for nothing,
   // which only happens in the last partial batch of a solve.
-  const int latched = PERSIST ? p_latched : (DUMP ? 0 : sload(a.ctrl + LDC_CTRL_DONE));
-  const int step0 = PERSIST ? p_step0 : sload(a.ctrl + LDC_CTRL_STEP);
-  const double adt = a.alpha * (PERSIST ? p_dt : sload(a.scal + LDC_SCAL_DT));
+  const int latched = DUMP ? 0 : sload(a.ctrl + LDC_CTRL_DONE);
+  const int step0 = sload(a.ctrl + LDC_CTRL_STEP);
+  const double adt = a.alpha * sload(a.scal + LDC_SCAL_DT);
 
   // ---- pointwise operands of the epilogue, issued now so that they land under the MFMAs ----------
   // threads 0..255 own node (i, j) of the tile; in a tile with an index-(M-1) job threads 256.. own
@@ -590,31 +614,31 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
   if (owner || edge_thr) {
     if (owner) {     // stage input at a tile node: from the packed twin (block (I, J), element (ti, tj))
       const size_t kin = ((size_t)(I * NB + J) << 8) + (size_t)((((tj >> 2) << 4) + ti) << 2) + (tj & 3);
-      uin = gl_t<PERSIST>(a.UinK, kin);
-      vin = gl_t<PERSIST>(a.VinK, kin);
+      uin = gl(a.UinK, kin);
+      vin = gl(a.VinK, kin);
     } else {         // node of index M-1: row-major forms (never rewritten by the tiles)
-      uin = gl_t<PERSIST>(colnode ? a.UinT : a.Uin, colnode ? ijT : ij);
-      vin = gl_t<PERSIST>(colnode ? a.VinT : a.Vin, colnode ? ijT : ij);
+      uin = gl(colnode ? a.UinT : a.Uin, colnode ? ijT : ij);
+      vin = gl(colnode ? a.VinT : a.Vin, colnode ? ijT : ij);
     }
     if (!DUMP) {
-      u0 = gl_t<PERSIST>(colnode ? a.U0T : a.U0, colnode ? ijT : ij);
-      v0 = gl_t<PERSIST>(colnode ? a.V0T : a.V0, colnode ? ijT : ij);
+      u0 = gl(colnode ? a.U0T : a.U0, colnode ? ijT : ij);
+      v0 = gl(colnode ? a.V0T : a.V0, colnode ? ijT : ij);
     }
-    if (owner && !DUMP && a.Pout != nullptr) p0 = gl_t<PERSIST>(a.P0, ij);
+    if (owner && !DUMP && a.Pout != nullptr) p0 = gl(a.P0, ij);
     if (!GPV && (owner || VEL == 1)) {
       const size_t ip = colnode ? (size_t)M * LD + i : ij;
-      px = gl_t<PERSIST>(a.PX, ip); py = gl_t<PERSIST>(a.PY, ip);
+      px = gl(a.PX, ip); py = gl(a.PY, ip);
     }
     if (a.tail) {
-      dxl = gl_t<PERSIST>(a.DxL, i); d2xl = gl_t<PERSIST>(a.D2xL, i); dyl = gl_t<PERSIST>(a.DyL, j); d2yl = gl_t<PERSIST>(a.D2yL, j);
-      ue = gl_t<PERSIST>(a.Uin, (size_t)m1 * LD + j); ve = gl_t<PERSIST>(a.Vin, (size_t)m1 * LD + j);    // east-wall row
-      un_ = gl_t<PERSIST>(a.UinT, (size_t)m1 * LD + i); vn_ = gl_t<PERSIST>(a.VinT, (size_t)m1 * LD + i);  // lid column, read along the transposed copy
-      if (DIAG == 2) { we = gl_t<PERSIST>(a.W, (size_t)m1 * LD + j); wn = gl_t<PERSIST>(a.WT, (size_t)m1 * LD + i); }
+      dxl = gl(a.DxL, i); d2xl = gl(a.D2xL, i); dyl = gl(a.DyL, j); d2yl = gl(a.D2yL, j);
+      ue = gl(a.Uin, (size_t)m1 * LD + j); ve = gl(a.Vin, (size_t)m1 * LD + j);    // east-wall row
+      un_ = gl(a.UinT, (size_t)m1 * LD + i); vn_ = gl(a.VinT, (size_t)m1 * LD + i);  // lid column, read along the transposed copy
+      if (DIAG == 2) { we = gl(a.W, (size_t)m1 * LD + j); wn = gl(a.WT, (size_t)m1 * LD + i); }
     }
-    lidv = gl_t<PERSIST>(a.ulid, i);
+    lidv = gl(a.ulid, i);
     // (only loaded here: their product is formed in the epilogue -- arithmetic on a loaded value at this point
     //  makes the wave wait for every load issued so far, first fragments included: +1.2 us before the K loop)
-    if (LAST || DIAG != 0) { wxi = gl_t<PERSIST>(a.wx, i); wyj = gl_t<PERSIST>(a.wy, j); }
+    if (LAST || DIAG != 0) { wxi = gl(a.wx, i); wyj = gl(a.wy, j); }
   }
 
   LDC_STAMP(1);
@@ -638,13 +662,13 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
   // Loads one group ahead (A/B ping-pong); with the packed twins one group ahead is enough (the probe delivers
   // the whole 278 KB of a tile in ~1.9 us whatever the depth, profiles/r01_aql_probe.log).
   for (int n = 0; n < ng; n += 2) {
-    if (GP) load_extra<PERSIST>(fx, o, NB, I, J, gk(n), lane);          // first: loads return in issue order
-    load_role<PERSIST>(fb, o, NB, I, J, gk(n + 1 < ng ? n + 1 : n), lane);   // clamped: harmless reload
+    if (GP) load_extra<false>(fx, o, NB, I, J, gk(n), lane);          // first: loads return in issue order
+    load_role<false>(fb, o, NB, I, J, gk(n + 1 < ng ? n + 1 : n), lane);   // clamped: harmless reload
     mfma_role<GP, NA>(fa, fx, acc, a.ablate, o.x4);
     if (anyE && !(a.ablate & 4096)) edge_group<VEL, GP>(ea, fa, fx, o, erow, n, lane, rowE, colE, cornE);
     if (n + 1 < ng) {
-      if (GP) load_extra<PERSIST>(fx, o, NB, I, J, gk(n + 1), lane);
-      load_role<PERSIST>(fa, o, NB, I, J, gk(n + 2 < ng ? n + 2 : n + 1), lane);
+      if (GP) load_extra<false>(fx, o, NB, I, J, gk(n + 1), lane);
+      load_role<false>(fa, o, NB, I, J, gk(n + 2 < ng ? n + 2 : n + 1), lane);
       mfma_role<GP, NA>(fb, fx, acc, a.ablate, o.x4);
       if (anyE && !(a.ablate & 4096)) edge_group<VEL, GP>(ea, fb, fx, o, erow, n + 1, lane, rowE, colE, cornE);
     }
@@ -717,10 +741,7 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
     }
     if (a.tail) {
       // k = M-1 lies outside the MFMA range: exact rank-1 completion of every contraction
-      ux += dxl * ue; vx += dxl * ve;
-      uy += un_ * dyl; vy += vn_ * dyl;
-      lu += d2xl * ue + un_ * d2yl;
-      lv += d2xl * ve + vn_ * d2yl;
+      nm_tail(ux, vx, uy, vy, lu, lv, dxl, d2xl, dyl, d2yl, ue, ve, un_, vn_);
     }
     if (GPV) {
       px = valid ? C(0, 4) : 0.0;   // row M-1 of T1T/T2T meets a zero column of GxF/IxF: no completion term
@@ -738,12 +759,12 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
     }
     if (DIAG == 2) {
       double gx = C(0, 4), gy = C(1, 4);                 // sg.py:546-547
-      if (a.tail) { gx += dxl * we; gy += wn * dyl; }
-      dsum = valid ? wq * (gx * gx + gy * gy) : 0.0;
+      if (a.tail) { gx = nm_madd(dxl, we, gx); gy = nm_madd(wn, dyl, gy); }
+      dsum = valid ? wq * nm_sq2(gx, gy) : 0.0;
     }
-    const double Ru = -(uin * ux + vin * uy) - px + a.nu * lu;
-    const double Rv = -(uin * vx + vin * vy) - py + a.nu * lv;
-    const double Rp = -a.beta2 * (ux + vy);
+    const double Ru = nm_momentum(uin, vin, ux, uy, px, a.nu, lu);
+    const double Rv = nm_momentum(uin, vin, vx, vy, py, a.nu, lv);
+    const double Rp = nm_continuity(a.beta2, ux, vy);
     if (DUMP) {
       if (valid) {
         a.dump[0][ij] = ux; a.dump[1][ij] = uy; a.dump[2][ij] = vx; a.dump[3][ij] = vy;
@@ -752,7 +773,7 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
         if (interior) a.dump[10][ij] = Rp;
       }
     } else if (owner) {
-      un = u0 + adt * Ru; vn = v0 + adt * Rv;
+      un = nm_madd(adt, Ru, u0); vn = nm_madd(adt, Rv, v0);
       // walls first, lid last (sg.py:348-385): the lid row wins the two top corners
       if (!valid) { un = 0.0; vn = 0.0; }
       else if (j == M - 1) { un = lidv; vn = 0.0; }
@@ -762,7 +783,7 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
         st_out(a.Vout + ij, vn, a.wt);
       }
       if (a.Pout != nullptr && !(a.ablate & 32)) {
-        const double pn = interior ? (p0 + adt * Rp) : 0.0;
+        const double pn = interior ? nm_madd(adt, Rp, p0) : 0.0;
         st_out(a.Pout + ij, pn, a.wt);
         tp[ti * 17 + tj] = pn;
       }
@@ -777,7 +798,7 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
         sums[PS_RU2] = valid ? Ru * Ru : 0.0;
         sums[PS_RV2] = valid ? Rv * Rv : 0.0;
         sums[PS_RP2] = interior ? Rp * Rp : 0.0;
-        sums[PS_E] = valid ? wq * (un * un + vn * vn) : 0.0;
+        sums[PS_E] = valid ? wq * nm_sq2(un, vn) : 0.0;
         maxs[0] = fabs(un);
         maxs[1] = fabs(vn);
       }
@@ -785,7 +806,7 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
       // node of index M-1: its value is a boundary condition and never changes
       sums[PS_U02] = u0 * u0; sums[PS_V02] = v0 * v0;
       sums[PS_RU2] = Ru * Ru; sums[PS_RV2] = Rv * Rv;
-      sums[PS_E] = wq * (u0 * u0 + v0 * v0);
+      sums[PS_E] = wq * nm_sq2(u0, v0);
       maxs[0] = fabs(u0); maxs[1] = fabs(v0);
     }
   }
@@ -826,11 +847,9 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
       for (int m = 0; m < kStageWaves; ++m) x += red[lane + 64 * m];
       x = wave_sum(x);
       double* slab = (DIAG == 1 ? a.partZ0 : a.partP0) + (size_t)((step0 > 0 ? step0 - 1 : 0) & 1) * a.stride;
-      if (lane == 0) {
-        if (PERSIST) st_out(slab + (size_t)bx * LDC_NPART, x, 1); else slab[(size_t)bx * LDC_NPART] = x;
-      }
+      if (lane == 0) slab[(size_t)bx * LDC_NPART] = x;
     }
-    if (!PERSIST && DIAG == 2 && bx == 0 && tid == 0) {      // Z and P partials of state `step0` are complete
+    if (DIAG == 2 && bx == 0 && tid == 0) {      // Z and P partials of state `step0` are complete
       a.ctrl[LDC_CTRL_PDONE] = step0;
       a.ctrl[LDC_CTRL_DROWS] = nblk;
     }
@@ -849,16 +868,16 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
 #pragma unroll
       for (int m = 0; m < kStageWaves; ++m) x += red[wv * kStageThreads + lane + 64 * m];
       x = wave_sum(x);
-      if (lane == 0) { if (PERSIST) st_out(dst + wv, x, 1); else dst[wv] = x; }       // kStageWaves == PS_NSUM
+      if (lane == 0) dst[wv] = x;       // kStageWaves == PS_NSUM
     }
     if (wv < 2) {
       double x = 0.0;
 #pragma unroll
       for (int m = 0; m < kStageWaves; ++m) x = fmax(x, red[(PS_NSUM + wv) * kStageThreads + lane + 64 * m]);
       x = wave_max(x);
-      if (lane == 0) { if (PERSIST) st_out(dst + PS_NSUM + wv, x, 1); else dst[PS_NSUM + wv] = x; }
+      if (lane == 0) dst[PS_NSUM + wv] = x;
     }
-    if (!PERSIST && bx == 0 && tid == 0) a.ctrl[LDC_CTRL_STEP] = step0 + 1;   // one more state update done
+    if (bx == 0 && tid == 0) a.ctrl[LDC_CTRL_STEP] = step0 + 1;   // one more state update done
   }
   LDC_STAMP(6);
 }
@@ -869,7 +888,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
   // fields it needs next (+3 us per launch)
   const StageArgs a = BATCH ? a_arr[blockIdx.y] : a_val;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  stage_body<GPV, LAST, DUMP, BATCH, DIAG, false>(a, (int)blockIdx.x, (int)gridDim.x, lds, 0, 0, 0.0);
+  stage_body<GPV, LAST, DUMP, BATCH, DIAG>(a, (int)blockIdx.x, (int)gridDim.x, lds);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -895,8 +914,8 @@ struct FinalArgs {
 
 __device__ __forceinline__ double next_dt(double umax, double vmax, const FinalArgs& a) {
   const double um = fmax(umax, a.lid), vm = fmax(vmax, 1e-10);
-  const double lx = (um + sqrt(um * um + a.beta2)) / a.hx + a.nu / (a.hx * a.hx);
-  const double ly = (vm + sqrt(vm * vm + a.beta2)) / a.hy + a.nu / (a.hy * a.hy);
+  const double lx = (um + sqrt(nm_madd(um, um, a.beta2))) / a.hx + a.nu / (a.hx * a.hx);
+  const double ly = (vm + sqrt(nm_madd(vm, vm, a.beta2))) / a.hy + a.nu / (a.hy * a.hy);
   return a.cfl / (lx + ly);
 }
 
@@ -931,7 +950,10 @@ __device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t, 
   const bool flush = a.with_diag && (flushed < iter) && (pdone >= iter);
   const bool crit = a.do_critical && !done && (step > iter);       // iteration `iter` awaits its record
   if (!flush && !crit) return;
-  const bool active = t < kThreads;
+  // Rows r >= number of rows contribute the neutral 0.0, so with at most 64 rows only wave 0 has anything to load and
+  // to reduce; the other waves' totals are exactly the 0.0 they would have computed.
+  const bool one_wave = PERSIST && a.nblk4 <= 64 && drows <= 64;
+  const bool active = t < (one_wave ? 64 : kThreads);
   double v[PS_N + 2];
 #pragma unroll
   for (int q = 0; q < PS_N + 2; ++q) v[q] = 0.0;
@@ -961,6 +983,9 @@ __device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t, 
       v[q] = is_max ? wave_max(v[q]) : wave_sum(v[q]);
       if ((t & 63) == 0) sm[q * NW + (t >> 6)] = v[q];
     }
+  } else if (one_wave && t < kThreads && (t & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < PS_N + 2; ++q) sm[q * NW + (t >> 6)] = 0.0;
   }
   __syncthreads();
   // Cross-wave totals, their square roots and the next dt by SEPARATE lanes, in parallel: this block is the critical
@@ -1277,7 +1302,7 @@ __device__ __forceinline__ bool grid_sync(unsigned* sync, unsigned& phase, unsig
 // wave-cooperative dot product, `a` written by other work-groups in this launch
 __device__ __forceinline__ double dot_rows_coh(const double* a, const double* b, int n, int lane) {
   double s = 0.0;
-  for (int k = lane; k < n; k += 64) s += gl_t<true>(a, (size_t)k) * b[k];
+  for (int k = lane; k < n; k += 64) s = nm_madd(gl_t<true>(a, (size_t)k), b[k], s);
   return wave_sum(s);
 }
 
@@ -1337,16 +1362,415 @@ __device__ __forceinline__ void post_phase(const PostArgs& a, const double* P, c
   }
   __syncthreads();
   if (tile_wave) {
-    const int tr = tid >> 4, tc = tid & 15;
-    const size_t o = (size_t)(c0 + tr) * LD + r0 + tc;
-    const bool ok = (c0 + tr < M) && (r0 + tc < M);
-    st_out(a.T1T + o, ok ? t1[tc * 17 + tr] : 0.0, 1);
-    st_out(a.T2T + o, ok ? t2[tc * 17 + tr] : 0.0, 1);
-    const int pl = tid >> 2, pr = pl & 15, pc = 4 * (pl >> 4) + (tid & 3);
-    const size_t kbT = ((size_t)(J * a.NB + I) << 8) + tid;
-    const bool okp = (c0 + pr < M) && (r0 + pc < M);
-    st_out(a.T1TK + kbT, okp ? t1[pc * 17 + pr] : 0.0, 1);
-    st_out(a.T2TK + kbT, okp ? t2[pc * 17 + pr] : 0.0, 1);
+    // Only the packed twins, block (J, I), 16 bytes per store: threads 0..127 T1T, 128..255 T2T (thread h of a half
+    // stores doubles 2h, 2h+1 of the 2-KB block = elements (row pr, columns pc, pc+1)).  The row-major tile body of
+    // T1T / T2T has no reader (the fragments come from the twins, the index-(M-1) jobs read row M-1 only).
+    (void)LD;
+    const int hh = tid & 127, pl = hh >> 1, pr = pl & 15, pc = 4 * (pl >> 4) + 2 * (hh & 1);
+    const size_t kbT = ((size_t)(J * a.NB + I) << 8) + 2 * hh;
+    const bool ok0 = (c0 + pr < M) && (r0 + pc < M), ok1 = (c0 + pr < M) && (r0 + pc + 1 < M);
+    const double* tt = tid < 128 ? t1 : t2;
+    st_out2((tid < 128 ? a.T1TK : a.T2TK) + kbT, ok0 ? tt[pc * 17 + pr] : 0.0, ok1 ? tt[(pc + 1) * 17 + pr] : 0.0, 1);
+  }
+}
+
+// ---- tile-resident stage ------------------------------------------------------------------------------------
+// Inside the persistent kernel a work-group owns tile (I, J) for the whole launch, so everything that belongs to the
+// tile alone STAYS in the work-group: a thread keeps phi^n, its stage input, grad p^n and p^n of its node in
+// registers from stage to stage and from iteration to iteration; the constants of the epilogue (quadrature weights,
+// lid profile, last operator columns, boundary values of index M-1) sit in LDS tables filled once; the constant
+// rows of index M-1 that feed the index-(M-1) jobs are staged in LDS once.  Per stage a work-group then issues only
+// the loads that are communication -- the operand fragments of other tiles' state (sc1) -- and only the stores other
+// work-groups read: the packed twins of its tile (16-byte write-through stores), p row-major (the transforms' edge
+// rows read it), omega on the row / column of index M-1, its partial sums.  The launch body issues ~230 vector-memory
+// instructions per work-group and stage, most of them pointwise 8-byte accesses to the tile's own data, and that
+// issue rate is what bounds it at small N (profiles/r02_persist_v0_stamps.log); here it is ~70.
+// The row-major forms of phi are written once, when the launch ends.
+// The arithmetic -- K split over the eight waves, order of every sum, every formula of the epilogue -- is stage_body's,
+// so a trajectory is bit-identical to the launch path's (tests/test_gpu_persistent.py).
+enum { TB_DXL = 0, TB_D2XL, TB_LID, TB_WX, TB_UN, TB_VN, TB_DYL, TB_D2YL, TB_WY, TB_UE, TB_VE, TB_N };
+constexpr int kTabStride = 24;          // 17 entries used: 16 of the tile + index M-1
+constexpr int kTileSlots = 8;           // rows of index M-1 per wave: A0 A1 A2 B0 B1 B2 (as StageLds) + omega row / column
+
+struct TileLds {
+  static constexpr int NA = 5;
+  static constexpr int RED = kStageWaves * NA * 4 * 64;
+  static constexpr int EDGE = RED;                                    // [wave][15][16]
+  static constexpr int TILE = EDGE + kStageWaves * 15 * 16;           // 4 x 16 x 17 (u, v, omega, p)
+  static constexpr int SCR = TILE + 4 * 16 * 17;
+  static constexpr int EROW = SCR + kStageWaves * PS_N;               // [wave][kTileSlots][4 groups][16]
+  static constexpr int TAB = EROW + kStageWaves * kTileSlots * 64;    // [TB_N][kTabStride]
+  static constexpr int WEN = TAB + TB_N * kTabStride;                 // omega at (M-1, j) and (i, M-1): [2][kTabStride]
+  static constexpr int TOTAL = WEN + 2 * kTabStride;
+  static constexpr size_t BYTES = sizeof(double) * TOTAL;
+};
+static_assert(TileLds::BYTES <= kLdsLimit - 1024, "tile-resident kernel LDS (plus its static words)");
+
+struct TileCtx {
+  // tile and thread geometry
+  int M, LD, T, NB, tail, m1, I, J, r0, c0;
+  int tid, lane, wv, role, kq, ng;
+  bool rowE, colE, cornE, anyE;          // block-uniform: which index-(M-1) job this tile carries
+  bool owner, edge_thr, colnode;
+  int ekind, eidx, i, j, ti, tj, tabi, tabj;
+  // the node's state, resident
+  double u0, v0, p0;                     // phi^n
+  double uc, vc;                         // stage input (= output of the previous stage)
+  double px, py;                         // grad p^n (SG: of stage 1, used by stages 2-4)
+};
+
+__device__ __forceinline__ void tile_setup(TileCtx& c, const StageArgs& a, int bx, double* lds) {
+  c.M = a.M; c.LD = a.LD; c.T = a.T; c.NB = a.NB; c.tail = a.tail; c.m1 = a.M - 1;
+  c.tid = threadIdx.x; c.lane = c.tid & 63; c.wv = c.tid >> 6; c.role = c.wv >> 2; c.kq = c.wv & 3;
+  c.ng = (c.T - c.kq + 3) / 4;
+  tile_of_block(bx, c.T, c.I, c.J);
+  c.r0 = 16 * c.I; c.c0 = 16 * c.J;
+  const bool etile = a.tail != 0;
+  c.rowE = etile && (c.I == c.J);
+  c.colE = etile && (c.J == (c.I + 1) % c.T);
+  c.cornE = etile && (c.T >= 3 ? (c.I == 0 && c.J == 2) : (c.I == 0 && c.J == 0));
+  c.anyE = c.rowE || c.colE || c.cornE;
+  c.ti = 4 * (c.wv & 3) + (c.lane >> 4); c.tj = c.lane & 15;
+  c.owner = c.tid < 256;
+  c.ekind = (c.tid - 256) >> 4; c.eidx = (c.tid - 256) & 15;
+  c.edge_thr = !c.owner && ((c.ekind == 0 && c.rowE) || (c.ekind == 1 && c.colE) || (c.ekind == 2 && c.eidx == 0 && c.cornE));
+  c.i = c.owner ? (c.r0 + c.ti) : ((c.ekind == 1) ? (c.r0 + c.eidx) : c.m1);
+  c.j = c.owner ? (c.c0 + c.tj) : ((c.ekind == 0) ? (c.c0 + c.eidx) : c.m1);
+  c.tabi = c.owner ? c.ti : ((c.ekind == 1) ? c.eidx : 16);
+  c.tabj = c.owner ? c.tj : ((c.ekind == 0) ? c.eidx : 16);
+  c.colnode = !c.owner && c.ekind == 1;
+  const int M = c.M, LD = c.LD, m1 = c.m1;
+  // ---- constant tables: entry e < 16 is the tile's own index, entry 16 is index M-1
+  if (c.tid < TB_N * 17) {
+    const int t = c.tid / 17, e = c.tid % 17;
+    const bool by_i = t <= TB_VN;
+    const int idx = e < 16 ? ((by_i ? c.r0 : c.c0) + e) : m1;
+    const size_t em = (size_t)m1 * LD + idx;
+    double x;
+    switch (t) {
+      case TB_DXL: x = a.DxL[idx]; break;
+      case TB_D2XL: x = a.D2xL[idx]; break;
+      case TB_LID: x = a.ulid[idx]; break;
+      case TB_WX: x = a.wx[idx]; break;
+      case TB_UN: x = a.UinT[em]; break;        // lid column, along the transposed copy
+      case TB_VN: x = a.VinT[em]; break;
+      case TB_DYL: x = a.DyL[idx]; break;
+      case TB_D2YL: x = a.D2yL[idx]; break;
+      case TB_WY: x = a.wy[idx]; break;
+      case TB_UE: x = a.Uin[em]; break;         // east-wall row
+      default: x = a.Vin[em]; break;
+    }
+    lds[TileLds::TAB + t * kTabStride + e] = x;
+  }
+  // ---- the node's state
+  c.u0 = c.v0 = c.p0 = c.px = c.py = 0.0;
+  const size_t ij = (size_t)c.i * LD + c.j, ijT = (size_t)c.j * LD + c.i;
+  if (c.owner || c.edge_thr) {
+    c.u0 = c.colnode ? a.U0T[ijT] : a.U0[ij];
+    c.v0 = c.colnode ? a.V0T[ijT] : a.V0[ij];
+    if (c.owner) c.p0 = a.P0[ij];
+  }
+  c.uc = c.u0; c.vc = c.v0;
+  // ---- job tiles: the CONSTANT rows of index M-1 (operators, boundary values of the state), once
+  if (c.anyE) {
+    double* erow = lds + TileLds::EROW + c.wv * kTileSlots * 64;
+    const int h = c.lane & 1, q = (c.lane >> 1) & 3, gi = (c.lane >> 3) & 3, sl = c.lane >> 5;
+    const size_t off = (size_t)m1 * LD + 16 * (c.kq + 4 * gi) + 4 * q + 2 * h;
+    const bool live = (c.kq + 4 * gi) < c.T;
+    const bool needA = c.rowE || c.cornE, needB = c.colE || c.cornE;
+    const double* row0 = c.role == 0 ? a.Dx : a.Uin;
+    const double* row1 = c.role == 0 ? a.D2x : a.Vin;
+    const double* row2 = c.role == 0 ? a.GxF : a.IxF;
+    const double* row3 = c.role == 0 ? a.UinT : a.Dy;
+    const double* row4 = c.role == 0 ? a.VinT : a.D2y;
+    if (live && needA) dma16<false>((sl ? row1 : row0) + off, erow);
+    if (live && (sl ? needB : needA)) dma16<false>((sl ? row3 : row2) + off, erow + 128);
+    if (live && needB && sl == 0) dma16<false>(row4 + off, erow + 256);
+  }
+  (void)M;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// GPV / LAST / DIAG as stage_body.  step0: state index this iteration started from (parity of the Z / P slabs).
+// stp: timing experiments (per-wave cycle stamps of this stage), or null
+template <bool GPV, bool LAST, int DIAG>
+__device__ __forceinline__ void tile_stage(TileCtx& c, const StageArgs a, double* lds, const int bx, const int step0,
+                                           const double dt, double* stp) {
+#define LDC_PSTAMP(k) do { if (stp != nullptr && c.lane == 0) \
+    stp[((size_t)bx * kStageWaves + c.wv) * 8 + (k)] = (double)__builtin_amdgcn_s_memtime(); } while (0)
+  LDC_PSTAMP(0);
+  constexpr bool GP = GPV || (DIAG == 2);
+  static_assert(!(GPV && DIAG == 2), "stage 2 of SG carries no pressure contraction");
+  constexpr int VEL = LAST ? 1 : (DIAG == 1 ? 2 : 0);
+  constexpr int NA = GP ? 5 : 4;
+  constexpr int SA2 = (DIAG == 2) ? 6 : 2, SB2 = (DIAG == 2) ? 7 : 5;
+  double* red = lds;
+  const int tid = c.tid, lane = c.lane, wv = c.wv, role = c.role, kq = c.kq, ng = c.ng;
+  const int M = c.M, LD = c.LD, T = c.T, m1 = c.m1, NB = c.NB, I = c.I, J = c.J, r0 = c.r0, c0 = c.c0;
+  const bool rowE = c.rowE && (GP || VEL != 0), colE = c.colE && (GP || VEL != 0), cornE = c.cornE && (GP || VEL != 0);
+  const bool anyE = rowE || colE || cornE;
+  const bool owner = c.owner, edge_thr = c.edge_thr && (GP || VEL != 0);
+  const int ekind = c.ekind, eidx = c.eidx, i = c.i, j = c.j, ti = c.ti, tj = c.tj;
+  const double adt = a.alpha * dt;
+
+  RoleOps o;
+  o.ablate = 0;
+  o.role = role;
+  o.x4 = (DIAG == 2) ? (role == 0 ? 1 : 2) : 0;
+  if (role == 0) {
+    o.A0 = a.DxK; o.A1 = a.D2xK; o.B0 = a.UinTK; o.B1 = a.VinTK;
+    o.A2 = (DIAG == 2) ? a.DxK : a.GxFK; o.B2 = (DIAG == 2) ? a.WTK : a.T1TK;
+  } else {
+    o.A0 = a.UinK; o.A1 = a.VinK; o.B0 = a.DyK; o.B1 = a.D2yK;
+    o.A2 = (DIAG == 2) ? a.WK : a.IxFK; o.B2 = (DIAG == 2) ? a.DyK : a.T2TK;
+  }
+  auto gk = [&](int n) { return kq + 4 * n; };
+  double* erow = lds + TileLds::EROW + wv * kTileSlots * 64;
+
+  // ---- job tiles: the rows of index M-1 that CHANGE -- the pressure transforms (slot 5), omega (slots 6, 7)
+  if (anyE && (GPV || DIAG == 2)) {
+    const int h = lane & 1, q = (lane >> 1) & 3, gi = (lane >> 3) & 3, sl = lane >> 5;
+    const size_t off = (size_t)m1 * LD + 16 * (kq + 4 * gi) + 4 * q + 2 * h;
+    const bool live = (kq + 4 * gi) < T;
+    const bool needA = rowE || cornE, needB = colE || cornE;
+    if (GPV) {      // lanes 32..63 land in slot 5 (B2: T1T | T2T)
+      if (live && needB && sl == 1) dma16<true>((role == 0 ? a.T1T : a.T2T) + off, erow + 256);
+    } else {        // slot 6: omega row (role 1, A2); slot 7: omega^T row (role 0, B2)
+      if (live && sl == 0 && role == 1 && needA) dma16<true>(a.W + off, erow + 384);
+      if (live && sl == 1 && role == 0 && needB) dma16<true>(a.WT + off, erow + 384);
+    }
+  }
+  // omega on the row / column of index M-1 for the rank-1 completion of grad omega: one wave fetches, LDS serves
+  if (DIAG == 2 && c.tail && wv == 7 && lane < 34) {
+    const int e = lane % 17, which = lane / 17;
+    const int idx = e < 16 ? ((which == 0 ? c0 : r0) + e) : m1;
+    lds[TileLds::WEN + which * kTabStride + e] = gl_t<true>(which == 0 ? a.W : a.WT, (size_t)m1 * LD + idx);
+  }
+
+  // ---- fragments -----------------------------------------------------------------------------------
+  RoleFrags fa, fb;
+  ExtraFrags fx;
+  load_role<true>(fa, o, NB, I, J, ng > 0 ? gk(0) : 0, lane);
+  LDC_PSTAMP(1);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the LDS-direct rows have landed (see stage_body)
+  v4d acc[NA];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+  EdgeAcc ea;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) { ea.er[q] = 0.0; ea.ec[q] = 0.0; ea.ek[q] = 0.0; }
+  for (int n = 0; n < ng; n += 2) {
+    if (GP) load_extra<true>(fx, o, NB, I, J, gk(n), lane);
+    load_role<true>(fb, o, NB, I, J, gk(n + 1 < ng ? n + 1 : n), lane);
+    mfma_role<GP, NA>(fa, fx, acc, 0, o.x4);
+    if (anyE) edge_group<VEL, GP, SA2, SB2>(ea, fa, fx, o, erow, n, lane, rowE, colE, cornE);
+    if (n + 1 < ng) {
+      if (GP) load_extra<true>(fx, o, NB, I, J, gk(n + 1), lane);
+      load_role<true>(fa, o, NB, I, J, gk(n + 2 < ng ? n + 2 : n + 1), lane);
+      mfma_role<GP, NA>(fb, fx, acc, 0, o.x4);
+      if (anyE) edge_group<VEL, GP, SA2, SB2>(ea, fb, fx, o, erow, n + 1, lane, rowE, colE, cornE);
+    }
+  }
+
+  LDC_PSTAMP(2);
+  // ---- all partial results to LDS ---------------------------------------------------------------
+#pragma unroll
+  for (int q = 0; q < NA; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((wv * NA + q) * 4 + r) * 64 + lane] = acc[q][r];
+  if (anyE) {
+    double* er = lds + TileLds::EDGE + wv * 15 * 16;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      if ((q == 0 && VEL == 0) || (q >= 1 && q < 4 && VEL != 1) || (q == 4 && !GP)) continue;
+      if (rowE) { const double x = quad_sum(ea.er[q]); if (lane < 16) er[q * 16 + lane] = x; }
+      if (colE) { const double y = quad_sum(ea.ec[q]); if (lane < 16) er[(5 + q) * 16 + lane] = y; }
+      if (cornE) { const double z = quad_sum(ea.ek[q]); if (lane < 16) er[(10 + q) * 16 + lane] = z; }
+    }
+  }
+  __syncthreads();
+  LDC_PSTAMP(3);
+
+  auto rsum = [&](int rl, int q) {
+    const int w = wv & 3;
+    double x = red[(((rl * 4 + 0) * NA + q) * 4 + w) * 64 + lane];
+    x += red[(((rl * 4 + 1) * NA + q) * 4 + w) * 64 + lane];
+    x += red[(((rl * 4 + 2) * NA + q) * 4 + w) * 64 + lane];
+    x += red[(((rl * 4 + 3) * NA + q) * 4 + w) * 64 + lane];
+    return x;
+  };
+  auto esum = [&](int rl, int kind, int q, int idx) {
+    const double* base = lds + TileLds::EDGE + (kind * 5 + q) * 16 + idx;
+    double x = base[(rl * 4 + 0) * 15 * 16];
+    x += base[(rl * 4 + 1) * 15 * 16];
+    x += base[(rl * 4 + 2) * 15 * 16];
+    x += base[(rl * 4 + 3) * 15 * 16];
+    return x;
+  };
+  const double* tab = lds + TileLds::TAB;
+
+  double sums[PS_NSUM] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double maxs[2] = {0, 0};
+  double un = 0.0, vn = 0.0;
+  double dsum = 0.0;
+  double* tu = lds + TileLds::TILE;
+  double* tv = tu + 16 * 17;
+  double* tw = tv + 16 * 17;
+  double* tp = tw + 16 * 17;
+  const size_t ij = (size_t)i * LD + j;
+  const bool has_p = a.Pout != nullptr;
+
+  if (owner || edge_thr) {
+    const double uin = c.uc, vin = c.vc, u0 = c.u0, v0 = c.v0, p0 = c.p0;
+    double px = c.px, py = c.py;
+    const double wq = tab[TB_WX * kTabStride + c.tabi] * tab[TB_WY * kTabStride + c.tabj];
+    const double lidv = tab[TB_LID * kTabStride + c.tabi];
+    auto C = [&](int rl, int q) { return owner ? rsum(rl, q) : esum(rl, ekind, q, eidx); };
+    const bool valid = (i < M) && (j < M);
+    const bool interior = (i >= 1) && (i <= M - 2) && (j >= 1) && (j <= M - 2);
+    const bool full = owner || VEL == 1;
+    double ux = 0, vx = 0, uy = 0, vy = 0, lu = 0, lv = 0;
+    if (full) {
+      ux = C(0, 0); vx = C(0, 1); lu = C(0, 2) + C(1, 1); lv = C(0, 3) + C(1, 3);
+      uy = C(1, 0); vy = C(1, 2);
+    } else if (VEL == 2) {
+      vx = C(0, 0); uy = C(1, 0);
+    }
+    double dxl = 0, dyl = 0;
+    if (c.tail) {
+      dxl = tab[TB_DXL * kTabStride + c.tabi]; dyl = tab[TB_DYL * kTabStride + c.tabj];
+      const double d2xl = tab[TB_D2XL * kTabStride + c.tabi], d2yl = tab[TB_D2YL * kTabStride + c.tabj];
+      const double ue = tab[TB_UE * kTabStride + c.tabj], ve = tab[TB_VE * kTabStride + c.tabj];
+      const double un_ = tab[TB_UN * kTabStride + c.tabi], vn_ = tab[TB_VN * kTabStride + c.tabi];
+      nm_tail(ux, vx, uy, vy, lu, lv, dxl, d2xl, dyl, d2yl, ue, ve, un_, vn_);
+    }
+    if (GPV) {
+      px = valid ? C(0, 4) : 0.0;
+      py = valid ? C(1, 4) : 0.0;
+      c.px = px; c.py = py;
+    }
+    if (DIAG == 1) {
+      const double w = valid ? (vx - uy) : 0.0;
+      if (owner) tw[ti * 17 + tj] = w;
+      else { st_out(a.W + ij, w, 1); st_out(a.WT + (size_t)j * LD + i, w, 1); }
+      dsum = valid ? wq * w * w : 0.0;
+    }
+    if (DIAG == 2) {
+      double gx = C(0, 4), gy = C(1, 4);
+      if (c.tail) {
+        const double we = lds[TileLds::WEN + c.tabj], wn = lds[TileLds::WEN + kTabStride + c.tabi];
+        gx = nm_madd(dxl, we, gx); gy = nm_madd(wn, dyl, gy);
+      }
+      dsum = valid ? wq * nm_sq2(gx, gy) : 0.0;
+    }
+    const double Ru = nm_momentum(uin, vin, ux, uy, px, a.nu, lu);
+    const double Rv = nm_momentum(uin, vin, vx, vy, py, a.nu, lv);
+    const double Rp = nm_continuity(a.beta2, ux, vy);
+    if (owner) {
+      un = nm_madd(adt, Ru, u0); vn = nm_madd(adt, Rv, v0);
+      if (!valid) { un = 0.0; vn = 0.0; }
+      else if (j == M - 1) { un = lidv; vn = 0.0; }
+      else if (i == 0 || i == M - 1 || j == 0) { un = 0.0; vn = 0.0; }
+      if (has_p) {
+        const double pn = interior ? nm_madd(adt, Rp, p0) : 0.0;
+        st_out(a.Pout + ij, pn, 1);        // row-major: the transforms' rows of index M-1 contract whole rows of p
+        tp[ti * 17 + tj] = pn;
+        if (LAST) c.p0 = pn;
+      }
+      tu[ti * 17 + tj] = un;
+      tv[ti * 17 + tj] = vn;
+      c.uc = un; c.vc = vn;
+      if (LAST) {
+        const double du = un - u0, dv = vn - v0;
+        sums[PS_DU2] = valid ? du * du : 0.0;
+        sums[PS_DV2] = valid ? dv * dv : 0.0;
+        sums[PS_U02] = valid ? u0 * u0 : 0.0;
+        sums[PS_V02] = valid ? v0 * v0 : 0.0;
+        sums[PS_RU2] = valid ? Ru * Ru : 0.0;
+        sums[PS_RV2] = valid ? Rv * Rv : 0.0;
+        sums[PS_RP2] = interior ? Rp * Rp : 0.0;
+        sums[PS_E] = valid ? wq * nm_sq2(un, vn) : 0.0;
+        maxs[0] = fabs(un);
+        maxs[1] = fabs(vn);
+        c.u0 = un; c.v0 = vn;
+      }
+    } else if (LAST) {
+      sums[PS_U02] = u0 * u0; sums[PS_V02] = v0 * v0;
+      sums[PS_RU2] = Ru * Ru; sums[PS_RV2] = Rv * Rv;
+      sums[PS_E] = wq * nm_sq2(u0, v0);
+      maxs[0] = fabs(u0); maxs[1] = fabs(v0);
+    }
+  }
+  LDC_PSTAMP(4);
+  __syncthreads();
+  LDC_PSTAMP(5);
+  if (owner) {
+    // packed twins of this tile: what the other work-groups' fragments read (see stage_body)
+    const int hh = tid & 127, pl = hh >> 1, pr = pl & 15, pc = 4 * (pl >> 4) + 2 * (hh & 1);
+    const size_t kb = ((size_t)(I * NB + J) << 8) + 2 * hh, kbT = ((size_t)(J * NB + I) << 8) + 2 * hh;
+    const int e = pr * 17 + pc, eT = pc * 17 + pr;
+    if (tid < 128) {
+      st_out2(a.UoutK + kb, tu[e], tu[e + 1], 1); st_out2(a.UoutTK + kbT, tu[eT], tu[eT + 17], 1);
+      if (DIAG == 1) { st_out2(a.WK + kb, tw[e], tw[e + 1], 1); st_out2(a.WTK + kbT, tw[eT], tw[eT + 17], 1); }
+    } else {
+      st_out2(a.VoutK + kb, tv[e], tv[e + 1], 1); st_out2(a.VoutTK + kbT, tv[eT], tv[eT + 17], 1);
+      if (has_p) st_out2(a.PoutK + kb, tp[e], tp[e + 1], 1);
+    }
+  }
+  if (DIAG != 0) {
+    red[tid] = dsum;
+    __syncthreads();
+    if (wv == 0) {
+      double x = 0.0;
+#pragma unroll
+      for (int m = 0; m < kStageWaves; ++m) x += red[lane + 64 * m];
+      x = wave_sum(x);
+      double* slab = (DIAG == 1 ? a.partZ0 : a.partP0) + (size_t)((step0 > 0 ? step0 - 1 : 0) & 1) * a.stride;
+      if (lane == 0) st_out(slab + (size_t)bx * LDC_NPART, x, 1);
+    }
+  }
+  if (LAST) {
+#pragma unroll
+    for (int q = 0; q < PS_NSUM; ++q) red[q * kStageThreads + tid] = sums[q];
+    red[PS_UMAX * kStageThreads + tid] = maxs[0];
+    red[PS_VMAX * kStageThreads + tid] = maxs[1];
+    __syncthreads();
+    double* dst = a.partials + (size_t)bx * LDC_NPART;
+    {
+      double x = 0.0;
+#pragma unroll
+      for (int m = 0; m < kStageWaves; ++m) x += red[wv * kStageThreads + lane + 64 * m];
+      x = wave_sum(x);
+      if (lane == 0) st_out(dst + wv, x, 1);
+    }
+    if (wv < 2) {
+      double x = 0.0;
+#pragma unroll
+      for (int m = 0; m < kStageWaves; ++m) x = fmax(x, red[(PS_NSUM + wv) * kStageThreads + lane + 64 * m]);
+      x = wave_max(x);
+      if (lane == 0) st_out(dst + PS_NSUM + wv, x, 1);
+    }
+  }
+  LDC_PSTAMP(6);
+}
+
+// when the launch ends: the row-major forms of phi (and their transposed copies) from the resident registers
+__device__ __forceinline__ void tile_flush(const TileCtx& c, const StageArgs& a, double* lds) {
+  double* tu = lds + TileLds::TILE;
+  double* tv = tu + 16 * 17;
+  __syncthreads();
+  if (c.owner) {
+    const size_t ij = (size_t)c.i * c.LD + c.j;
+    a.Uout[ij] = c.u0; a.Vout[ij] = c.v0;
+    tu[c.ti * 17 + c.tj] = c.u0; tv[c.ti * 17 + c.tj] = c.v0;
+  }
+  __syncthreads();
+  if (c.owner) {
+    const int tr = c.tid >> 4, tc = c.tid & 15;
+    const size_t ot = (size_t)(c.c0 + tr) * c.LD + c.r0 + tc;
+    a.UoutT[ot] = tu[tc * 17 + tr];
+    a.VoutT[ot] = tv[tc * 17 + tr];
   }
 }
 
@@ -1386,7 +1810,8 @@ __global__ __launch_bounds__(kStageThreads, 2) void trial_kernel(const TrialArgs
       S.abort = 0;
     }
   }
-  __syncthreads();
+  TileCtx c;
+  tile_setup(c, LDC_TRIAL_ARG(StageArgs, st[0]), bx, lds);      // ends with a work-group barrier
   unsigned phase = 0;
   constexpr int D1 = DIAGV ? 1 : 0, D2 = DIAGV ? 2 : 0;
   // the transforms of one pressure array as a phase (smoother mode: PA / PB / PA after stages 1-3; always: P)
@@ -1396,37 +1821,44 @@ __global__ __launch_bounds__(kStageThreads, 2) void trial_kernel(const TrialArgs
     const double* PK = which < 0 ? pq.PK : LDC_TRIAL_ARG(const double*, PstK[which < 0 ? 0 : which]);
     post_phase(pq, P, PK, bx, nblk, lds, tid);
   };
+  // A phase's argument block is fetched BEFORE the barrier that precedes the phase: the scalar loads are in flight
+  // while the work-group waits for its peers instead of in front of the first fragment loads.
+  StageArgs a_next = LDC_TRIAL_ARG(StageArgs, st[0]);
   for (int it = 0; it < n_iters; ++it) {
     if (S.done != 0) break;                      // every work-group holds the same latch
     const int step0 = S.step;
     const double dt = S.dt;
+    double* const stq = (stamps != nullptr && it == n_iters - 1) ? stamps + (size_t)nblk * 64 : nullptr;
     LDC_TSTAMP(0);
-    stage_body<true, false, false, false, D1, true>(LDC_TRIAL_ARG(StageArgs, st[0]), bx, nblk, lds, 0, step0, dt);
+    tile_stage<true, false, D1>(c, a_next, lds, bx, step0, dt, stq);
     LDC_TSTAMP(1);
+    a_next = LDC_TRIAL_ARG(StageArgs, st[1]);
     if (!grid_sync(sync, phase, nblk, tid, &S)) return;
     LDC_TSTAMP(2);
     if (SP) {
       transforms(0);
       if (!grid_sync(sync, phase, nblk, tid, &S)) return;
     }
-    stage_body<SP, false, false, false, D2, true>(LDC_TRIAL_ARG(StageArgs, st[1]), bx, nblk, lds, 0, step0, dt);
+    tile_stage<SP, false, D2>(c, a_next, lds, bx, step0, dt, stq ? stq + (size_t)nblk * 64 : nullptr);
     if (DIAGV && tid == 0) { S.pdone = step0; S.drows = nblk; }     // Z and P partials of state `step0` are complete
     LDC_TSTAMP(3);
+    a_next = LDC_TRIAL_ARG(StageArgs, st[2]);
     if (!grid_sync(sync, phase, nblk, tid, &S)) return;
     LDC_TSTAMP(4);
     if (SP) {
       transforms(1);
       if (!grid_sync(sync, phase, nblk, tid, &S)) return;
     }
-    stage_body<SP, false, false, false, 0, true>(LDC_TRIAL_ARG(StageArgs, st[2]), bx, nblk, lds, 0, step0, dt);
+    tile_stage<SP, false, 0>(c, a_next, lds, bx, step0, dt, stq ? stq + (size_t)nblk * 128 : nullptr);
     LDC_TSTAMP(5);
+    a_next = LDC_TRIAL_ARG(StageArgs, st[3]);
     if (!grid_sync(sync, phase, nblk, tid, &S)) return;
     LDC_TSTAMP(6);
     if (SP) {
       transforms(2);
       if (!grid_sync(sync, phase, nblk, tid, &S)) return;
     }
-    stage_body<SP, true, false, false, 0, true>(LDC_TRIAL_ARG(StageArgs, st[3]), bx, nblk, lds, 0, step0, dt);
+    tile_stage<SP, true, 0>(c, a_next, lds, bx, step0, dt, stq ? stq + (size_t)nblk * 192 : nullptr);
     if (tid == 0) S.step = step0 + 1;            // one more state update done
     LDC_TSTAMP(7);
     if (!grid_sync(sync, phase, nblk, tid, &S)) return;
@@ -1435,8 +1867,10 @@ __global__ __launch_bounds__(kStageThreads, 2) void trial_kernel(const TrialArgs
     LDC_TSTAMP(9);
     transforms(-1);
     LDC_TSTAMP(10);
+    a_next = LDC_TRIAL_ARG(StageArgs, st[0]);
     if (it + 1 < n_iters && !grid_sync(sync, phase, nblk, tid, &S)) return;
   }
+  tile_flush(c, LDC_TRIAL_ARG(StageArgs, st[3]), lds);
   if (bx == 0 && tid == 0) {
     const FinalArgs fa = LDC_TRIAL_ARG(FinalArgs, post.fin);
     fa.ctrl[LDC_CTRL_DONE] = S.done; fa.ctrl[LDC_CTRL_ITER] = S.iter; fa.ctrl[LDC_CTRL_STEP] = S.step;
@@ -1950,7 +2384,7 @@ int launch_closing_diagnostics(ldc_solver* s, hipStream_t st) {
 }
 
 // ---- persistent trial kernel ------------------------------------------------------------------------------
-constexpr size_t kTrialLdsBytes = StageLds<true, true>::BYTES;     // the largest carve of the stage variants
+constexpr size_t kTrialLdsBytes = TileLds::BYTES;
 static_assert(kTrialLdsBytes <= kLdsLimit, "trial kernel LDS");
 static_assert(kTrialLdsBytes >= sizeof(double) * kThreads * (PS_N + 2), "finalize scratch fits");
 
@@ -1981,8 +2415,7 @@ TrialArgs make_trial_args(const ldc_solver* s, int n_iters, int with_diag) {
   for (int k = 0; k < 4; ++k) {
     ta.st[k] = make_stage_args(s, k);
     ta.st[k].wt = 1;              // every store of state is write-through: it is what publishes it
-    ta.st[k].ablate = s->stamps ? 64 : 0;     // timing experiments: per-wave stamps of stage k behind the phase stamps
-    ta.st[k].dump[0] = s->stamps ? s->stamps + (size_t)(k + 1) * s->nt * 64 : nullptr;
+    ta.st[k].ablate = 0;
   }
   int grid = 0;
   ta.post = make_post_args(s, s->p.P, 0, 1, with_diag, &grid);
@@ -2268,7 +2701,10 @@ int ldc_solver_enqueue(ldc_solver* s, int n_iters, int with_diag, void* stream) 
   { const int e = on_own_device(s); if (e) return e; }
   with_diag = with_diag ? 1 : 0;
   hipStream_t st = as_stream(stream);
-  if (n_iters > 0 && use_persistent(s)) {
+  // (a single iteration always goes launch by launch: nothing to gain, and it is the form the host uses for the first
+  //  iteration after an upload, when phi^n may still carry other values on the row / column of index M-1 than the
+  //  stage buffers do -- the tile-resident kernel stages those boundary values ONCE, from phi^n)
+  if (n_iters > 1 && use_persistent(s)) {
     const int e = launch_trial(s, n_iters, with_diag, st);
     if (e) return e;
     return with_diag ? launch_closing_diagnostics(s, st) : 0;

@@ -16,6 +16,7 @@ LIB_PATH = Path(os.environ.get("LDC_HIP_LIB", _PKG / "lib" / "libldc_hip.so"))
 REC_LEN, CTRL_LEN, SCAL_LEN, NPART = 8, 8, 8, 12
 SYNC_LEN, SYNC_GIVEUP = 64, 32
 ABI_VERSION = 3
+PERSIST_AUTO_TILES = 0      # LDC_PERSIST_AUTO_TILES of include/ldc_hip.h (auto mode picks the persistent kernel up to here)
 REC_REL, REC_RU, REC_RV, REC_RP, REC_E, REC_Z, REC_P, REC_DT = range(8)
 CTRL_DONE, CTRL_ITER = 0, 1
 SCAL_DT, SCAL_UMAX, SCAL_VMAX = 0, 1, 2

@@ -22,6 +22,15 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE J
               limit: the 4-us K loop of the stage kernel runs at ~65 TFLOP/s.
 * cpu_baseline : the NumPy oracle (a port of the reference, pinned to its golden vectors)
               timed on this host's cores for a bounded sample of the same workload.
+* timed region: EXACTLY K iterations between barrier + synchronize on both sides, max over ranks -- repeated
+              until at least 0.25 s have been timed (K = 20 lasts one millisecond: a single such region measures
+              the host's launch latency, not the device); `ms_per_step` is the MEDIAN region / K, `reps` says how
+              many regions there were, `launch_path` what the K iterations were enqueued as ("graph": hipGraph
+              replays of min(32, K)-iteration captures that divide K, "graph+eager" when K has a remainder,
+              "persistent": one launch of the persistent trial kernel).
+* farm      : a second, sweep-shaped measurement for the multi-GPU runs -- every rank advances a BATCH of
+              `trials_per_gpu` equal-N trials with shared launches (what main.py does with the trials a rank owns
+              in the Hydra multirun / Optuna search), value = trial-iterations/s over all ranks.
 """
 from __future__ import annotations
 
@@ -51,12 +60,21 @@ def flops_per_step(N: int, diagnostics: bool) -> float:
     return f
 
 
-def make_solver(N, Re, device):
+def graph_iters_for(K: int) -> int:
+    """Iterations per hipGraph capture so that K iterations are whole replays where possible: the largest
+    divisor of K that is <= 32 (K itself when K <= 32); below 8 the captures get too short to amortise a
+    replay, then 32 with an eager remainder."""
+    best = max(d for d in range(1, min(K, 32) + 1) if K % d == 0)
+    return best if best >= 8 or best == K else 32
+
+
+def make_solver(N, Re, device, graph_iters=32, persistent=-1):
     from solvers.spectral.sg import SGSolver
     return SGSolver(name="spectral", Re=Re, lid_velocity=1.0, Lx=1.0, Ly=1.0, nx=N, ny=N,
                     tolerance=0.0, max_iterations=10**9, basis_type="chebyshev", CFL=1.5,
                     beta_squared=5.0, corner_treatment="smoothing", corner_smoothing=0.15,
-                    multigrid="none", device=device, check_every=8192, graph_iters=32)
+                    multigrid="none", device=device, check_every=8192, graph_iters=graph_iters,
+                    persistent=persistent)
 
 
 def timed_iterations(s, K, diagnostics, barrier):
@@ -74,6 +92,43 @@ def timed_iterations(s, K, diagnostics, barrier):
     barrier()
     t1 = time.perf_counter()
     return t1 - t0, e0.elapsed_time(e1) * 1e-3
+
+
+def timed_regions(s, K, diagnostics, dist, min_seconds=0.25, max_reps=2000):
+    """Regions of exactly K iterations (each bracketed as the contract says, max over ranks) until `min_seconds`
+    have been timed; returns (median seconds per region, median event seconds, number of regions)."""
+    walls, evs, total = [], [], 0.0
+    while (total < min_seconds and len(walls) < max_reps) or len(walls) < 3:
+        w, e = timed_iterations(s, K, diagnostics, dist.barrier)
+        w = dist.max_float(w)                 # every rank sees the same number, so all leave the loop together
+        walls.append(w); evs.append(e)
+        total += w
+    walls.sort(); evs.sort()
+    return walls[len(walls) // 2], evs[len(evs) // 2], len(walls)
+
+
+def farm_rate(N, B, device, dist, seconds=0.3):
+    """Sweep-shaped load: B equal-N trials per rank advanced by shared launches (solvers.spectral.batched);
+    returns trial-iterations per second of this rank's batch and the iterations timed."""
+    import torch
+    from solvers.spectral.batched import BatchedSGSolver
+    kw = dict(name="spectral", lid_velocity=1.0, Lx=1.0, Ly=1.0, nx=N, ny=N, tolerance=0.0, max_iterations=10**9,
+              basis_type="chebyshev", CFL=1.5, beta_squared=5.0, corner_treatment="smoothing", multigrid="none",
+              device=device, check_every=4096, graph_iters=32)
+    trials = [dict(kw, Re=1000.0, corner_smoothing=0.02 + 0.01 * q) for q in range(B)]
+    b = BatchedSGSolver(trials)
+    b.run_iterations(64, diagnostics=False)                      # edge fix, graph build
+    K = 512
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds or n == 0:
+        b.run_iterations(K, diagnostics=False)
+        n += K
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    b.close()
+    return B * n / dt, n
 
 
 def stage_kernel_time(s, bursts=20, pairs_per_burst=100):
@@ -187,6 +242,27 @@ def pmc_traffic(N):
     return (k["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)) if k else (None, None)
 
 
+def pmc_mfma_util(N, launch_seconds):
+    """MFMA utilisation of the dominant kernel from the committed SQ-counter pass (profiles/r*_pmc.json, written by
+    tools/pmc_summarize.py): SQ_VALU_MFMA_BUSY_CYCLES per launch (busy cycles of the matrix pipes summed over the
+    SIMDs: 64 per fp64 MFMA) over the SIMD-cycles of a launch -- 1024 SIMDs at the 2.4 GHz peak clock -- for the launch
+    time measured live in this run; `mfma_util_profiled` is the same quotient with the (longer) launch time of the
+    profiled pass itself.  None when no such pass is committed for this size."""
+    import glob
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))]
+    if N != 256 or not files:
+        return None
+    for f in reversed(files):
+        with open(f) as fh:
+            k = json.load(fh)["kernels"].get("stage_kernel<false, false, false, false, 0>", {})
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in k:
+            busy = k["SQ_VALU_MFMA_BUSY_CYCLES"]
+            return {"mfma_util": busy / (launch_seconds * 2.4e9 * 1024), "mfma_util_profiled": k.get("mfma_util"),
+                    "mfma_busy_cycles_per_launch": busy, "mfma_util_source": os.path.relpath(f, ROOT),
+                    "sq_wait_inst_frac": k.get("sq_wait_inst_frac"), "sq_wait_any_frac": k.get("sq_wait_any_frac")}
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,6 +271,8 @@ def main():
     ap.add_argument("--N", type=int, default=WORKLOAD["N"])
     ap.add_argument("--Re", type=float, default=WORKLOAD["Re"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-farm", action="store_true", help="skip the batched-trials (sweep-shaped) measurement")
+    ap.add_argument("--persistent", type=int, default=-1, help="-1 auto, 0 launch per stage, 1 persistent kernel")
     a = ap.parse_args()
 
     import torch
@@ -213,19 +291,32 @@ def main():
     barrier()
     g._paths()
 
-    s = make_solver(a.N, a.Re, f"cuda:{local}")
+    gi = graph_iters_for(a.steps)
+    s = make_solver(a.N, a.Re, f"cuda:{local}", graph_iters=gi, persistent=a.persistent)
     s._begin(0.0)
-    # warm-up (also instantiates both hipGraphs)
-    timed_iterations(s, max(a.warmup, 64), True, barrier)
-    timed_iterations(s, 64, False, barrier)
+    from solvers.spectral import ldc_lib as L
+    persistent = (a.persistent == 1) or (a.persistent == -1 and s.T * s.T <= L.PERSIST_AUTO_TILES)
+    launch_path = "persistent" if persistent else ("graph" if a.steps % gi == 0 else "graph+eager")
+    # warm-up (also instantiates both hipGraphs): W untimed steps, at least two full captures
+    timed_iterations(s, max(a.warmup, 2 * gi), True, barrier)
+    timed_iterations(s, 2 * gi, False, barrier)
 
-    wall, ev = timed_iterations(s, a.steps, True, barrier)
-    wall_so, _ = timed_iterations(s, a.steps, False, barrier)
-    wall, wall_so = dist.max_float(wall), dist.max_float(wall_so)
+    wall, ev, reps = timed_regions(s, a.steps, True, dist)
+    wall_so, _, _ = timed_regions(s, a.steps, False, dist)
     ctrl = s.d["ctrl"].cpu().numpy()
     assert int(ctrl[0]) == 0, "latch fired during the bench (tolerance is 0: must not happen)"
     rec = s.d["rec"].cpu().numpy()
     assert bool((rec == rec).all()), "non-finite history record: the timed run diverged"
+
+    farm = None
+    if not a.no_farm:
+        fN, fB = 128, 4                       # config 5's trial shape: N = 128, four trials fill the 256 CUs
+        rate, n_it = farm_rate(fN, fB, f"cuda:{local}", dist)
+        rates = dist.all_gather_object(rate)
+        farm = {"value": float(sum(rates)), "unit": "trial-iterations/s", "n_gpus": world, "trials_per_gpu": fB, "N": fN,
+                "per_gpu": [float(r) for r in rates], "iterations_timed_per_trial": n_it,
+                "workload": f"{fB} batched SG trials of N={fN} per GPU (shared launches, step()-only loop), "
+                            "the per-rank load of main.py's sweep farm"}
 
     out = None
     if rank == 0:
@@ -238,7 +329,8 @@ def main():
         out = {
             "metric": "steady-state time-steps/sec at N=256 Re=1000",
             "value": world * a.steps / wall, "unit": "steps/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": 1e3 * wall / a.steps, "higher_is_better": True,
+            "warmup": a.warmup, "ms_per_step": 1e3 * wall / a.steps, "reps": reps, "launch_path": launch_path,
+            "graph_iters": gi, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"solver=spectral (SG) N={a.N} Re={a.Re:g} fp64, full solve() iteration "
                                    "(dt, 4 RK stages + BCs, change/residual norms, E/Z/P), fluid from rest",
@@ -253,6 +345,10 @@ def main():
                          "traffic_source": traffic_src, "flops_per_launch": f_launch, "launch_us": t_stage * 1e6,
                          "peak_measured": peak_meas, "frac_of_measured": achieved / peak_meas},
         }
+        out["farm"] = farm
+        mfma = pmc_mfma_util(a.N, t_stage)
+        if mfma is not None:
+            out["roofline"].update(mfma)
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(a.N, a.Re)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]

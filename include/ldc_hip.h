@@ -187,7 +187,9 @@ int ldc_solver_set_graph_iters(ldc_solver *s, int iters_per_graph);
 /* trial kernel -- ALL n_iters iterations in ONE launch of T*T work-groups that keep their tile and meet at a    */
 /* counter barrier per stage (needs desc->sync and T*T <= CUs of the device, else LDC_E_ARG); -1 (default):      */
 /* persistent when it is available and T*T <= LDC_PERSIST_AUTO_TILES.  Same arithmetic either way: records and   */
-/* fields are bit-identical.                                                                                     */
+/* fields are bit-identical.  The persistent kernel reads the boundary values of index M-1 (tail layout) once,   */
+/* from U / UT / V / VT: they must equal those of the stage buffers UA.. / UB.. (they do after the first          */
+/* iteration that follows an upload; a call with n_iters == 1 always runs launch by launch).                      */
 #define LDC_PERSIST_AUTO_TILES 0
 int ldc_solver_set_persistent(ldc_solver *s, int mode);
 /* 0, or LDC_E_SYNC when a persistent launch of this handle gave up a barrier wait (a work-group was not         */

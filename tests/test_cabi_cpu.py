@@ -28,6 +28,14 @@ def test_header_and_exports_agree(lib):
     assert L.ldc_version() == lib.ABI_VERSION == 3
 
 
+def test_python_constants_match_the_header(lib):
+    hdr = (ROOT / "include" / "ldc_hip.h").read_text()
+    val = lambda name: int(re.search(rf"{name}\s*=?\s*(-?\d+)", hdr).group(1))        # noqa: E731
+    assert val("#define LDC_PERSIST_AUTO_TILES") == lib.PERSIST_AUTO_TILES
+    assert val("LDC_SYNC_GIVEUP") == lib.SYNC_GIVEUP and val("LDC_SYNC_LEN") == lib.SYNC_LEN
+    assert val("#define LDC_NPART") == lib.NPART and val("#define LDC_ABI_VERSION") == lib.ABI_VERSION
+
+
 def test_struct_size_matches_header(lib):
     # 4 int32 + 7 double + 4 int32 + (37 + 27 packed twins) ptr + int64 + 4 ptr (scal, ctrl, rec, sync)
     assert C.sizeof(lib.Problem) == 16 + 56 + 16 + (37 + 27) * 8 + 8 + 32

@@ -31,6 +31,56 @@ def test_batched_iterations_equal_individual_runs(N):
     b.close()
 
 
+@pytest.mark.parametrize("N,Re,K", [(32, 100, 500), (64, 400, 1000)])
+def test_batched_trial_vs_reference_fixture(golden_dir, N, Re, K):
+    """A trial INSIDE a batch (other trials with other Re / lid profiles around it) against the reference's own
+    K-step trajectory: state <= 1e-12, dt <= 1e-12 rel, norms / E / Z / P <= 1e-10 rel (the bar of
+    tests/test_gpu_parity.py::test_trajectory_vs_reference)."""
+    from solvers.spectral.batched import BatchedSGSolver
+    g = np.load(golden_dir / f"g4_traj_N{N}_Re{Re}_K{K}.npz")
+    rel = lambda a, b: np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)     # noqa: E731
+    trials = [kw(N, 250, 0.05), kw(N, Re, 0.15), kw(N, 50, 0.30, CFL=1.0), kw(N, Re, 0.15)]
+    b = BatchedSGSolver(trials)
+    recs = b.run_iterations(K)
+    for q in (1, 3):
+        s, rec = b.solvers[q], recs[q]
+        assert rec.shape == (K, 8)
+        assert np.max(np.abs(s.arrays.u - g["u"])) < 1e-12
+        assert np.max(np.abs(s.arrays.v - g["v"])) < 1e-12
+        assert np.max(np.abs(s.arrays.p - g["p"])) < 1e-12
+        assert rel(rec[:, 7], g["dt"]) < 1e-12
+        assert rel(rec[:, 1:4], g["res"]) < 1e-10
+        for col, key in ((4, "E"), (5, "Z"), (6, "P")):
+            assert rel(rec[:, col], g[key]) < 1e-10, key
+    assert not np.array_equal(b.solvers[0].arrays.u, b.solvers[1].arrays.u)      # the neighbours are different flows
+    b.close()
+
+
+def test_batched_trials_keep_their_own_iteration_caps():
+    """One process per trial in the reference: a sweep over solver.max_iterations gives every trial ITS cap.
+    In a batch the host latches a trial when it reaches its cap (code 3); state and history equal the
+    stand-alone capped solves, and the wall-time shares add up to the batch's wall time."""
+    from solvers.spectral.batched import BatchedSGSolver
+    from solvers.spectral.sg import SGSolver
+    trials = [kw(32, 100, max_iterations=150), kw(32, 100, max_iterations=700), kw(32, 400, max_iterations=333),
+              kw(32, 100, tolerance=1e-2, max_iterations=5000)]
+    b = BatchedSGSolver(trials)
+    ms = b.solve()
+    assert [m.iterations for m in ms[:3]] == [150, 700, 333] and not any(m.converged for m in ms[:3])
+    assert ms[3].converged and ms[3].iterations < 5000
+    for t, s, m in zip(trials, b.solvers, ms):
+        one = SGSolver(**t)
+        one.solve()
+        assert (m.iterations, m.converged) == (one.metrics.iterations, one.metrics.converged)
+        assert np.array_equal(s.fields.u, one.fields.u) and np.array_equal(s.fields.p, one.fields.p)
+        assert s.time_series.energy == one.time_series.energy
+        one.close()
+    assert sum(m.wall_time_seconds for m in ms) == pytest.approx(b.batch_seconds, rel=1e-9)
+    with pytest.raises(ValueError, match="diagnostics"):
+        BatchedSGSolver([kw(16, 100), kw(16, 100, diagnostics=False)]).solve()
+    b.close()
+
+
 def test_batched_solve_latches_each_trial_independently():
     """Three trials converge at different iterations; a fourth (N=16, Re=400 diverges with CFL 1.5,
     SURVEY section 5) leaves through the NaN latch.  All equal their stand-alone solves."""
@@ -90,6 +140,24 @@ def test_batched_fsg_equals_individual_fsg_solves():
         assert m.psi_min == one.metrics.psi_min and m.final_palinstrophy == one.metrics.final_palinstrophy
         one.close()
     assert all(m.converged for m in ms) and len({m.iterations for m in ms}) == 4
+    b.close()
+
+
+def test_batched_fsg_trial_vs_reference_fixture(golden_dir):
+    """A batched FSG trial against the reference's own capped two-level run (g8: cap300_N32_Re100)."""
+    import json
+    from solvers.spectral.batched import BatchedFSGSolver
+    g = np.load(golden_dir / "g8_fsg_runs.npz")
+    c = json.loads((golden_dir / "g8_fsg_runs.json").read_text())["cap300_N32_Re100"]
+    base = fsg_kw(32, 100.0, 0.15, tolerance=1e-6, max_iterations=300)
+    b = BatchedFSGSolver([fsg_kw(32, 400.0, 0.10, max_iterations=300), base, fsg_kw(32, 50.0, 0.3, max_iterations=300)])
+    ms = b.solve()
+    s, m, ref = b.solvers[1], ms[1], c["metrics"]
+    assert m.iterations == ref["iterations"] and m.converged == ref["converged"]
+    for f in ("u", "v", "p"):
+        assert np.max(np.abs(getattr(s.arrays, f) - g[f"cap300_N32_Re100_{f}"])) < 1e-10, f
+    for key in ("u_momentum_residual", "continuity_residual", "final_energy", "final_enstrophy", "psi_min"):
+        assert getattr(m, key) == pytest.approx(ref[key], rel=1e-7, abs=1e-9), key
     b.close()
 
 

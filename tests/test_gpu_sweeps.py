@@ -1,0 +1,116 @@
+"""BASELINE configs 4 and 5 THROUGH the launcher (main.py), checked against the reference's fixtures and the oracle.
+
+Config 4: ``-m N=64,128,256 Re=100,400,1000`` -- a grid sweep whose equal-N trials share their launches on a GPU
+(solvers.spectral.batched).  Config 5: the corner-smoothing search on ``spectral/fsg`` with the botella_vortex
+objective (conf/experiment/optimization/corner_smoothing.yaml:25,50-57) -- ask/tell rounds of batched FSG trials.
+The full-size runs take minutes to hours; here the same command lines run with iteration caps, and what they
+write (``results.json``, ``solution.vts``, ``sweep_results.json``) is compared with the reference's own
+trajectories (tests/golden/g4_*), with oracle runs on identical parameters, and with stand-alone solves."""
+import importlib.util
+import json
+
+import numpy as np
+import pytest
+
+from oracle import ldc_oracle as orc
+from conftest import PKG
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def launcher(tmp_path, monkeypatch):
+    spec = importlib.util.spec_from_file_location("ldc_main_sweeps", PKG / "main.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.chdir(tmp_path)
+
+    def run(argv):
+        before = set(tmp_path.glob("hydra_outputs/multirun/*/*"))
+        out = mod.main(argv)
+        new = sorted(set(tmp_path.glob("hydra_outputs/multirun/*/*")) - before)
+        assert len(new) == 1, new
+        return out, new[0]
+
+    return run
+
+
+def _fields(run_dir, M):
+    """u, v of solution.vts as [ix, iy] arrays (the file is y-slow / x-fast, reference base.py:464-549)."""
+    from solvers.vtkio import read_vts
+    g = read_vts(run_dir / "solution.vts")
+    return g["point_data"]["u"].reshape(M, M).T, g["point_data"]["v"].reshape(M, M).T
+
+
+def test_config4_batched_sweep_vs_reference_and_oracle(launcher, golden_dir):
+    """``-m N=64 Re=400,1000 max_iterations=1000``: two N=64 trials advanced by the same launches.  Re=400 after 1000
+    iterations is the reference's own trajectory fixture; Re=1000 is checked against the oracle."""
+    _, root = launcher(["-m", "N=64", "Re=400,1000", "max_iterations=1000"])
+    recs = json.loads((root / "sweep_results.json").read_text())
+    assert [(r["N"], r["Re"]) for r in recs] == [(64, 400), (64, 1000)]
+    assert all(r["metrics"]["iterations"] == 1000 and not r["metrics"]["converged"] for r in recs)
+    assert all(r["batch_size"] == 2 and r["solve_batch_size"] == 2 for r in recs)      # they DID share launches
+    g = np.load(golden_dir / "g4_traj_N64_Re400_K1000.npz")
+    u, v = _fields(root / "0", 65)
+    assert np.max(np.abs(u - g["u"].reshape(65, 65))) < 1e-12
+    assert np.max(np.abs(v - g["v"].reshape(65, 65))) < 1e-12
+    m = recs[0]["metrics"]
+    assert m["final_energy"] == pytest.approx(g["E"][-1], rel=1e-10)
+    assert m["final_enstrophy"] == pytest.approx(g["Z"][-1], rel=1e-10)
+    assert m["final_palinstrophy"] == pytest.approx(g["P"][-1], rel=1e-10)
+    assert m["u_momentum_residual"] == pytest.approx(g["res"][-1, 0], rel=1e-10)
+    vm = dict(zip((str(k) for k in g["vortex_keys"]), g["vortex_vals"]))
+    for key in ("psi_min", "psi_min_x", "psi_min_y", "omega_center", "omega_max"):
+        assert m[key] == pytest.approx(vm[key], rel=1e-9, abs=1e-9), key
+    o = orc.OracleSG(64, 1000.0)
+    for _ in range(1000):
+        o.step()
+    u, v = _fields(root / "1", 65)
+    assert np.max(np.abs(u - o.u)) < 1e-12 and np.max(np.abs(v - o.v)) < 1e-12
+    assert recs[1]["metrics"]["final_energy"] == pytest.approx(o.energy(), rel=1e-10)
+
+
+def test_config4_grid_shape_n64_to_n256(launcher):
+    """The literal config-4 grid, ``-m N=64,128,256 Re=100,400,1000``, capped at 40 iterations: nine trials in three
+    batches (one per N); one trial of each size against the oracle."""
+    _, root = launcher(["-m", "N=64,128,256", "Re=100,400,1000", "max_iterations=40"])
+    recs = json.loads((root / "sweep_results.json").read_text())
+    assert [(r["N"], r["Re"]) for r in recs] == [(n, re) for n in (64, 128, 256) for re in (100, 400, 1000)]
+    assert all(r["metrics"]["iterations"] == 40 and r["batch_size"] == 3 for r in recs)
+    for idx in (1, 5, 6):           # (64, 400), (128, 1000), (256, 100)
+        N, Re = recs[idx]["N"], recs[idx]["Re"]
+        o = orc.OracleSG(N, float(Re))
+        for _ in range(40):
+            o.step()
+        u, v = _fields(root / str(idx), N + 1)
+        assert np.max(np.abs(u - o.u)) < 1e-12 and np.max(np.abs(v - o.v)) < 1e-12, (N, Re)
+        assert recs[idx]["metrics"]["final_energy"] == pytest.approx(o.energy(), rel=1e-10)
+        assert recs[idx]["metrics"]["final_enstrophy"] == pytest.approx(o.enstrophy(), rel=1e-9)
+
+
+def test_config5_corner_smoothing_search_vs_oracle(launcher):
+    """``+experiment/optimization=corner_smoothing`` with the botella_vortex objective: 8 trials in rounds of 4
+    batched FSG solves (N=32: levels 16 -> 32, 300 iterations per level).  Trial 0 against the oracle's FSG driver
+    on the corner_smoothing the sampler drew; every trial's objective recomputed from its own vortex metrics."""
+    from types import SimpleNamespace
+    from solvers import validation as V
+    best, root = launcher(["+experiment/optimization=corner_smoothing", "N=32", "hydra.sweeper.n_trials=8",
+                           "hydra.sweeper.n_jobs=4", "max_iterations=300", "optuna.objective=botella_vortex"])
+    recs = json.loads((root / "sweep_results.json").read_text())
+    assert len(recs) == 8 and [r["trial_index"] for r in recs] == [0, 1, 2, 3, 0, 1, 2, 3]
+    assert all(r["batch_size"] == 4 and r["solver"] == "spectral_fsg" for r in recs)
+    cs = [r["overrides"]["solver.corner_smoothing"] for r in recs]
+    assert all(0.01 <= c <= 0.10 for c in cs) and len(set(cs)) == 8
+    assert all(r["params"]["corner_smoothing"] == c for r, c in zip(recs, cs))
+    assert all(r["metrics"]["iterations"] == 600 for r in recs)                  # both levels ran to the cap
+    lvl, total, conv = orc.oracle_fsg(32, 1000.0, max_iterations=300, corner_smoothing=cs[0])
+    assert total == 600 and not conv
+    u, v = _fields(root / "0", 33)
+    assert np.max(np.abs(u - lvl.u)) < 1e-10 and np.max(np.abs(v - lvl.v)) < 1e-10
+    assert recs[0]["metrics"]["final_energy"] == pytest.approx(lvl.energy(), rel=1e-9)
+    objs = [r["objective"] for r in recs]
+    assert all(isinstance(x, float) and np.isfinite(x) for x in objs) and best == pytest.approx(min(objs))
+    for r in recs:
+        m = SimpleNamespace(**r["metrics"])
+        assert r["objective"] == pytest.approx(V.compute_botella_vortex_objective(m, 1000), rel=1e-12)
+        assert r["objective_kind"] == "botella_vortex"

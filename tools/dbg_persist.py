@@ -1,0 +1,20 @@
+"""Where does the persistent path first differ from the launch path? (development aid)"""
+import os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "02689-advancednumericalalgorithmp3_amd", "src"))
+import numpy as np
+from solvers.spectral.sg import SGSolver
+N = int(sys.argv[1]); K = int(sys.argv[2]); diag = bool(int(sys.argv[3])); Re = float(sys.argv[4]) if len(sys.argv) > 4 else 400.0
+out = []
+for mode in (1, 0):
+    s = SGSolver(name="spectral", Re=Re, nx=N, ny=N, basis_type="chebyshev", CFL=1.5, tolerance=1e-6,
+                 max_iterations=10**9, check_every=256, graph_iters=16, persistent=mode)
+    rec = s.run_iterations(K, diagnostics=diag)
+    out.append((rec, s.arrays.u.copy(), s.arrays.v.copy(), s.arrays.p.copy()))
+    s.close()
+a, b = out
+names = ["rel", "Ru", "Rv", "Rp", "E", "Z", "P", "dt"]
+for c in range(8):
+    d = np.nonzero(a[0][:, c] != b[0][:, c])[0]
+    print(f"col {names[c]:3s}: {len(d)} rows differ", (f"first {d[0]}: {a[0][d[0], c]!r} vs {b[0][d[0], c]!r}" if len(d) else ""))
+for k, n in ((1, "u"), (2, "v"), (3, "p")):
+    print(n, "max abs diff", float(np.max(np.abs(a[k] - b[k]))))

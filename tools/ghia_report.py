@@ -23,6 +23,10 @@ ap.add_argument("--cases", default="64:100,64:400,64:1000")
 ap.add_argument("--max-iter", type=int, default=4_000_000)
 ap.add_argument("--tolerance", type=float, default=1e-6, help="1e-6 = the reference's default (conf/config.yaml:20)")
 ap.add_argument("--out", default="gpurun_out/ghia.json")
+ap.add_argument("--time-limit", type=float, default=0.0,
+                help="seconds per case; when it runs out the state is written to --checkpoint and the case is resumed by "
+                     "the next call that finds the file (a gpurun call lasts 20 minutes at most)")
+ap.add_argument("--checkpoint", default="", help="npz path of the resumable state (one case)")
 a = ap.parse_args()
 import threading  # noqa: E402
 
@@ -35,7 +39,7 @@ def heartbeat(stop, label):
 
 
 out = []
-if Path(a.out).exists() and a.tolerance != 1e-6:
+if Path(a.out).exists() and (a.tolerance != 1e-6 or a.checkpoint):
     out = json.loads(Path(a.out).read_text())           # append to an earlier (partial) run
 for case in a.cases.split(","):
     N, Re = (int(x) for x in case.split(":"))
@@ -46,7 +50,43 @@ for case in a.cases.split(","):
     stop = threading.Event()
     hb = threading.Thread(target=heartbeat, args=(stop, case), daemon=True)
     hb.start()
-    s.solve()
+    if a.time_limit > 0 and a.checkpoint:
+        # resumable form of LidDrivenCavitySolver.solve: same loop, state + control words saved when time runs out
+        import numpy as np
+        import torch
+        from solvers.base import WARMUP_ITERATIONS
+        ck = Path(a.checkpoint)
+        s._begin(a.tolerance)
+        spent, kept_tail = 0.0, None
+        if ck.exists():
+            z = np.load(ck)
+            assert (int(z["N"]), int(z["Re"])) == (N, Re)
+            s.set_state(u=z["u"], v=z["v"], p=z["p"])
+            s._begin(a.tolerance)                      # T1T / T2T of the restored pressure
+            s.d["ctrl"].copy_(torch.from_numpy(z["ctrl"]).to(s.device))
+            s.d["scal"].copy_(torch.from_numpy(z["scal"]).to(s.device))
+            spent = float(z["spent"])
+            print(f"  resumed {case} at iteration {int(z['ctrl'][1])} after {spent:.0f} s", flush=True)
+        done, total, last = 0, int(s.d["ctrl"].cpu().numpy()[1]), None
+        while total < a.max_iter and not done and time.perf_counter() - t0 < a.time_limit:
+            recs, done, total = s._advance(min(4096, a.max_iter - total))
+            if len(recs):
+                last = recs
+        wall = spent + time.perf_counter() - t0
+        if not done and total < a.max_iter:
+            ck.parent.mkdir(parents=True, exist_ok=True)
+            np.savez(ck, N=N, Re=Re, u=s.arrays.u, v=s.arrays.v, p=s.arrays.p, ctrl=s.d["ctrl"].cpu().numpy(),
+                     scal=s.d["scal"].cpu().numpy(), spent=wall)
+            stop.set()
+            print(f"  checkpoint {case}: iteration {total}, rel {last[-1, 0]:.3e}, {wall:.0f} s so far -> {ck}", flush=True)
+            s.close()
+            continue
+        s.history = last
+        s._store_results(last[-1:], total, done == 1, wall)
+        if ck.exists():
+            ck.unlink()
+    else:
+        s.solve()
     stop.set()
     m = s.metrics
     rec = dict(N=N, Re=Re, tolerance=a.tolerance, iterations=m.iterations, converged=m.converged, wall_time_seconds=m.wall_time_seconds,

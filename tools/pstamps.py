@@ -30,7 +30,7 @@ print(f"N={N} T={s.T} diag={diag}: cycles per phase (median over 5 launches); me
 for k, n in enumerate(names):
     print(f"  {n:8s} mean {d[:, k].mean():9.0f}  max {d[:, k].max():9.0f}   {d[:, k].mean() / 2400:7.2f} us")
 print(f"  total    {d.sum(axis=1).mean():9.0f}   {d.sum(axis=1).mean() / 2400:7.2f} us (without the closing barrier)")
-pts = ["entry->loads issued", "K loop", "partials->LDS+barrier", "epilogue", "barrier", "stores+reductions"]
+pts = ["entry->frags issued", "drain + K loop", "partials->LDS+barrier", "epilogue", "barrier", "stores+reductions"]
 for k in range(4):
     print(f"  inside stage {k + 1} (mean over work-groups and waves / max), cycles:")
     for q, n in enumerate(pts):
