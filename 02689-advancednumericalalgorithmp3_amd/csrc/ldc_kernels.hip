@@ -171,6 +171,35 @@ __device__ __forceinline__ double nm_momentum(double uin, double vin, double qx,
 __device__ __forceinline__ double nm_continuity(double beta2, double ux, double vy) { return -beta2 * (ux + vy); }
 #pragma clang fp contract(fast)
 
+// Two dot products that share their first row, a . b1 and a . b2, with every operand of the first 512 elements
+// requested BEFORE the first multiply: the plain loop waits for its loads once per trip (five trips at N = 256, each a
+// cold round trip: the rows of index M-1 of the pressure transforms took ~5 us this way and were the critical path of
+// the post launch).  Same multiply-adds per lane in the same order as dot_rows.
+template <bool COH>
+__device__ __forceinline__ void dot_rows2(const double* a, const double* b1, const double* b2, int n, int lane,
+                                          double& s1, double& s2) {
+  constexpr int U = 8;
+  double av[U], x1[U], x2[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int k = lane + 64 * u;
+    const bool in = k < n;
+    av[u] = in ? gl_t<COH>(a, (size_t)k) : 0.0;
+    x1[u] = in ? b1[k] : 0.0;
+    x2[u] = in ? b2[k] : 0.0;
+  }
+  double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (lane + 64 * u < n) { t1 = nm_madd(av[u], x1[u], t1); t2 = nm_madd(av[u], x2[u], t2); }
+  }
+  for (int k = lane + 64 * U; k < n; k += 64) {
+    const double x = gl_t<COH>(a, (size_t)k);
+    t1 = nm_madd(x, b1[k], t1); t2 = nm_madd(x, b2[k], t2);
+  }
+  s1 = wave_sum(t1); s2 = wave_sum(t2);
+}
+
 // wave-cooperative dot product of two contiguous rows (fixed order => deterministic)
 __device__ __forceinline__ double dot_rows(const double* a, const double* b, int n, int lane) {
   double s = 0.0;
@@ -241,6 +270,36 @@ __device__ __forceinline__ void tile_of_block(int b, int T, int& I, int& J) {
 }
 
 // ---------------------------------------------------------------------------------------
+// finalize arguments (the fold of the per-work-group partial sums: change norms, |R|, E, next dt, latch, record)
+// ---------------------------------------------------------------------------------------
+struct FinalArgs {
+  int nblk4, nblkZ, nblkP;   // rows in each slab
+  int with_diag, warmup, nan_guard, rec_cap;
+  int do_critical;           // 0: flush only
+  double cfl, beta2, nu, hx, hy, lid, tol;
+  const double *part4, *partZ0, *partP0;   // parity slabs: partZ0 + parity * stride
+  long long stride;
+  double* scal;
+  int* ctrl;
+  double* rec;
+};
+
+__device__ __forceinline__ double next_dt(double umax, double vmax, const FinalArgs& a) {
+  const double um = fmax(umax, a.lid), vm = fmax(vmax, 1e-10);
+  const double lx = (um + sqrt(nm_madd(um, um, a.beta2))) / a.hx + a.nu / (a.hx * a.hx);
+  const double ly = (vm + sqrt(nm_madd(vm, vm, a.beta2))) / a.hy + a.nu / (a.hy * a.hy);
+  return a.cfl / (lx + ly);
+}
+
+// Control block of one trial inside the persistent trial kernel (LDS; every work-group keeps its own, identical copy:
+// they all fold the same partial sums in the same order).  Mirrors ctrl[] / scal[] of the launch-per-stage path.
+struct TrialState {
+  int done, iter, step, flushed, pdone, drows;
+  int abort;                 // a bounded spin of a grid barrier gave up (LDC_E_SYNC): every thread leaves
+  double dt, umax, vmax;
+};
+
+// ---------------------------------------------------------------------------------------
 // RK stage kernel
 // ---------------------------------------------------------------------------------------
 struct StageArgs {
@@ -278,6 +337,90 @@ struct StageArgs {
 enum { PS_DU2 = 0, PS_DV2, PS_U02, PS_V02, PS_RU2, PS_RV2, PS_RP2, PS_E, PS_NSUM, PS_UMAX = PS_NSUM, PS_VMAX, PS_N };
 static_assert(PS_N <= LDC_NPART, "partials row too small");
 static_assert(PS_NSUM == 8, "stage-4 reduction assigns one wave per sum");
+
+// What ONE wave makes of the wave totals sm[q * 4 + w] (q < PS_N + 2 values, w < 4 waves): cross-wave totals, their
+// square roots and the next dt by SEPARATE lanes in parallel (eight fp64 square roots, the divisions and next_dt in a
+// row on one lane were most of the finalize block's tail), everything else uniformly on every lane through
+// readlane.  `writer`: lane 0 also stores the record, the control words and the scalars.  Results are uniform over
+// the wave.  The same function serves the finalize block of the post launch, the finalize kernel and the persistent
+// kernel: one arithmetic, one rounding.
+struct FinOut {
+  int latch;                 // 0, or the latch this iteration sets
+  int iter, flushed;         // control words after this call
+  double dt, umax, vmax;     // scalars after this call (unchanged when there was nothing to close)
+};
+__device__ __forceinline__ FinOut fin_decide_wave(const FinalArgs& a, const double* sm, const int lane, const bool crit,
+                                                  const bool flush, const int iter, const int flushed,
+                                                  const double dt_cur, const bool writer) {
+  constexpr int NW = kThreads / 64;
+  auto total = [&](int q) {
+    const bool is_max = (q == PS_UMAX || q == PS_VMAX);
+    double x = sm[q * NW];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) x = is_max ? fmax(x, sm[q * NW + w]) : (x + sm[q * NW + w]);
+    return x;
+  };
+  double xr = 0.0, xs = 0.0;
+  if (lane < PS_N + 2) {
+    xr = total(lane);
+    xs = (lane < PS_RP2 + 1) ? sqrt(xr) : 0.0;     // DU2, DV2, U02, V02, RU2, RV2, RP2
+  } else if (lane == 16 && crit) {
+    xr = next_dt(total(PS_UMAX), total(PS_VMAX), a);
+  }
+  double r[PS_N + 2], sq[PS_RP2 + 1];
+#pragma unroll
+  for (int q = 0; q < PS_N + 2; ++q) r[q] = lane_value(xr, q);
+#pragma unroll
+  for (int q = 0; q < PS_RP2 + 1; ++q) sq[q] = lane_value(xs, q);
+  const double dt_new = lane_value(xr, 16);
+  FinOut o;
+  o.latch = 0; o.iter = iter; o.flushed = flushed; o.dt = dt_cur; o.umax = 0.0; o.vmax = 0.0;
+  const bool w0 = writer && lane == 0;
+  if (flush) {
+    if (w0) {
+      double* rec = a.rec + (size_t)((iter - 1) % a.rec_cap) * LDC_REC_LEN;
+      rec[LDC_REC_Z] = 0.5 * r[PS_N];
+      rec[LDC_REC_P] = 0.5 * r[PS_N + 1];
+    }
+    o.flushed = iter;
+  }
+  if (crit) {
+    const double relu = sq[PS_DU2] / (sq[PS_U02] + 1e-12);
+    const double relv = sq[PS_DV2] / (sq[PS_V02] + 1e-12);
+    // Python's max(a, b) returns a unless b > a: a NaN in relv is dropped, one in relu sticks
+    const double rel = (relv > relu) ? relv : relu;
+    if (w0) {
+      double* rec = a.rec + (size_t)(iter % a.rec_cap) * LDC_REC_LEN;   // `iter` = 0-based index of this iteration
+      rec[LDC_REC_REL] = rel;
+      rec[LDC_REC_RU] = sq[PS_RU2];
+      rec[LDC_REC_RV] = sq[PS_RV2];
+      rec[LDC_REC_RP] = sq[PS_RP2];
+      rec[LDC_REC_E] = 0.5 * r[PS_E];
+      rec[LDC_REC_Z] = 0.0;
+      rec[LDC_REC_P] = 0.0;
+      rec[LDC_REC_DT] = dt_cur;
+    }
+    o.latch = (iter >= a.warmup && rel < a.tol) ? 1
+              : (a.nan_guard && !(fabs(rel) <= 1.79769313486231570815e308)) ? 2 : 0;
+    o.umax = r[PS_UMAX]; o.vmax = r[PS_VMAX]; o.dt = dt_new;
+    o.iter = iter + 1;
+    if (!a.with_diag) o.flushed = iter + 1;      // nothing to fold for this record
+  }
+  return o;
+}
+
+// the control words and scalars a closed iteration leaves behind (launch path: ctrl / scal in memory)
+__device__ __forceinline__ void fin_publish(const FinalArgs& a, const FinOut& o, const bool crit, const bool flush) {
+  if (flush || crit) a.ctrl[LDC_CTRL_FLUSHED] = o.flushed;
+  if (crit) {
+    a.scal[LDC_SCAL_UMAX] = o.umax;
+    a.scal[LDC_SCAL_VMAX] = o.vmax;
+    a.scal[LDC_SCAL_DT] = o.dt;
+    a.ctrl[LDC_CTRL_ITER] = o.iter;
+    if (o.latch) a.ctrl[LDC_CTRL_DONE] = o.latch;
+  }
+}
+
 
 #ifndef LDC_WT_MIN_TILES
 #define LDC_WT_MIN_TILES 1       // see st_out: write-through measured neutral-or-better at every size (tools/ab_*.py)
@@ -578,7 +721,6 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
     if (live && (sl ? needB : needA) && s23 != nullptr) dma16<false>(s23 + off, erow + 128);
     if (live && needB && s45 != nullptr) dma16<false>(s45 + off, erow + 256);
   }
-
   // ---- first fragments in flight before anything else ------------------------------------
   RoleFrags fa, fb;
   ExtraFrags fx;
@@ -651,6 +793,8 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
   // Batched launches: the work-groups of a trial whose latch has fired leave HERE, before the K loop, so that a
   // batch gets cheaper as its trials converge (trials of one batch can differ by 25 % in iteration count).  The
   // wait above keeps the prologue's loads in front of this branch (a return any earlier gets them sunk below it).
+  // (a latched stage 4 tells the post launch behind it that there is nothing new to transform: ctrl[LIVE])
+  if (LAST && latched != 0 && bx == 0 && tid == 0) a.ctrl[LDC_CTRL_LIVE] = 0;
   if (BATCH && latched != 0) return;
   // ---- contraction over k: this wave's quarter, loads one group ahead (A/B ping-pong) --------
   v4d acc[NA];
@@ -877,7 +1021,10 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
       x = wave_max(x);
       if (lane == 0) dst[PS_NSUM + wv] = x;
     }
-    if (bx == 0 && tid == 0) a.ctrl[LDC_CTRL_STEP] = step0 + 1;   // one more state update done
+    if (bx == 0 && tid == 0) {
+      a.ctrl[LDC_CTRL_STEP] = step0 + 1;   // one more state update done
+      a.ctrl[LDC_CTRL_LIVE] = 1;           // and a new pressure for the post launch to transform
+    }
   }
   LDC_STAMP(6);
 }
@@ -900,33 +1047,6 @@ __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs
 // then the palinstrophy kernel), so they are folded one launch later ("lagged flush") from
 // parity slabs; an idempotent flush launch at the end of every enqueue closes the last record.
 // ---------------------------------------------------------------------------------------
-struct FinalArgs {
-  int nblk4, nblkZ, nblkP;   // rows in each slab
-  int with_diag, warmup, nan_guard, rec_cap;
-  int do_critical;           // 0: flush only
-  double cfl, beta2, nu, hx, hy, lid, tol;
-  const double *part4, *partZ0, *partP0;   // parity slabs: partZ0 + parity * stride
-  long long stride;
-  double* scal;
-  int* ctrl;
-  double* rec;
-};
-
-__device__ __forceinline__ double next_dt(double umax, double vmax, const FinalArgs& a) {
-  const double um = fmax(umax, a.lid), vm = fmax(vmax, 1e-10);
-  const double lx = (um + sqrt(nm_madd(um, um, a.beta2))) / a.hx + a.nu / (a.hx * a.hx);
-  const double ly = (vm + sqrt(nm_madd(vm, vm, a.beta2))) / a.hy + a.nu / (a.hy * a.hy);
-  return a.cfl / (lx + ly);
-}
-
-// Control block of one trial inside the persistent trial kernel (LDS; every work-group keeps its own, identical copy:
-// they all fold the same partial sums in the same order).  Mirrors ctrl[] / scal[] of the launch-per-stage path.
-struct TrialState {
-  int done, iter, step, flushed, pdone, drows;
-  int abort;                 // a bounded spin of a grid barrier gave up (LDC_E_SYNC): every thread leaves
-  double dt, umax, vmax;
-};
-
 // Threads 0 .. kThreads-1 of one block do the work, sm holds kThreads * (PS_N + 2) doubles.
 // PERSIST = false: the finalize block of a post launch / the finalize kernel (256 threads, control words in ctrl/scal).
 // PERSIST = true : a phase of the persistent trial kernel.  ALL threads of the (larger) work-group call it (the
@@ -934,21 +1054,27 @@ struct TrialState {
 //   in this launch are read with coherent loads, and only the work-group with `writer` set stores the record.
 template <bool PERSIST>
 __device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t, TrialState* S, bool writer) {
-  __shared__ int fin_state[6];       // one reader: the decision below guards barriers
-  if (!PERSIST) {
-    if (t == 0) {
-      fin_state[0] = a.ctrl[LDC_CTRL_DONE]; fin_state[1] = a.ctrl[LDC_CTRL_ITER];
-      fin_state[2] = a.ctrl[LDC_CTRL_STEP]; fin_state[3] = a.ctrl[LDC_CTRL_FLUSHED];
-      fin_state[4] = a.ctrl[LDC_CTRL_PDONE]; fin_state[5] = a.ctrl[LDC_CTRL_DROWS];
-    }
-    __syncthreads();
-  }
-  const int done = PERSIST ? S->done : fin_state[0], iter = PERSIST ? S->iter : fin_state[1];
-  const int step = PERSIST ? S->step : fin_state[2], flushed = PERSIST ? S->flushed : fin_state[3];
-  const int pdone = PERSIST ? S->pdone : fin_state[4], drows = PERSIST ? S->drows : fin_state[5];
+  // Launch path: nobody writes the control words while this block runs (it is the only writer, at its end), so every
+  // wave reads them itself by scalar loads -- the same values for all, hence a block-uniform decision below.
+  const int done = PERSIST ? S->done : sload(a.ctrl + LDC_CTRL_DONE), iter = PERSIST ? S->iter : sload(a.ctrl + LDC_CTRL_ITER);
+  const int step = PERSIST ? S->step : sload(a.ctrl + LDC_CTRL_STEP);
+  const int flushed = PERSIST ? S->flushed : sload(a.ctrl + LDC_CTRL_FLUSHED);
+  const int pdone = PERSIST ? S->pdone : sload(a.ctrl + LDC_CTRL_PDONE), drows = PERSIST ? S->drows : sload(a.ctrl + LDC_CTRL_DROWS);
   // record iter-1 lacks Z, P, and the partial sums of state `iter` (its end state) are complete
   const bool flush = a.with_diag && (flushed < iter) && (pdone >= iter);
   const bool crit = a.do_critical && !done && (step > iter);       // iteration `iter` awaits its record
+  // Launch path: this thread's first partial-sum row is requested BEFORE the control words above are looked at (the
+  // compiler keeps the scalar loads and these in flight together): one cold round trip instead of two.  The rows
+  // are harmless to read whatever the decision turns out to be.
+  double pre[PS_N];
+#pragma unroll
+  for (int q = 0; q < PS_N; ++q) pre[q] = 0.0;
+  const bool pre_row = !PERSIST && a.do_critical && t < kThreads && t < a.nblk4;
+  if (pre_row) {
+    const double* p = a.part4 + (size_t)t * LDC_NPART;
+#pragma unroll
+    for (int q = 0; q < PS_N; ++q) pre[q] = gl(p, q);
+  }
   if (!flush && !crit) return;
   // Rows r >= number of rows contribute the neutral 0.0, so with at most 64 rows only wave 0 has anything to load and
   // to reduce; the other waves' totals are exactly the 0.0 they would have computed.
@@ -958,7 +1084,15 @@ __device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t, 
 #pragma unroll
   for (int q = 0; q < PS_N + 2; ++q) v[q] = 0.0;
   if (crit && active) {
-    for (int r = t; r < a.nblk4; r += kThreads) {
+    int r = t;
+    if (pre_row) {              // row t is already here
+#pragma unroll
+      for (int q = 0; q < PS_NSUM; ++q) v[q] += pre[q];
+      v[PS_UMAX] = fmax(v[PS_UMAX], pre[PS_UMAX]);
+      v[PS_VMAX] = fmax(v[PS_VMAX], pre[PS_VMAX]);
+      r += kThreads;
+    }
+    for (; r < a.nblk4; r += kThreads) {
       const double* p = a.part4 + (size_t)r * LDC_NPART;
 #pragma unroll
       for (int q = 0; q < PS_NSUM; ++q) v[q] += gl_t<PERSIST>(p, q);
@@ -967,7 +1101,6 @@ __device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t, 
     }
   }
   if (flush && active) {
-    // (loading these rows speculatively, together with the control words above, was measured: +0.7 us per iteration)
     const int par = (iter - 1) & 1;
     const double* pz = a.partZ0 + (size_t)par * a.stride;
     const double* pp = a.partP0 + (size_t)par * a.stride;
@@ -988,67 +1121,18 @@ __device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t, 
     for (int q = 0; q < PS_N + 2; ++q) sm[q * NW + (t >> 6)] = 0.0;
   }
   __syncthreads();
-  // Cross-wave totals, their square roots and the next dt by SEPARATE lanes, in parallel: this block is the critical
-  // path of the post launch and one lane doing eight fp64 square roots, the divisions and next_dt in a row is most of
-  // its tail.  Same operations on the same operands as the serial form: bit-identical.
-  __shared__ double fin_r[PS_N + 2], fin_sqrt[PS_N + 2], fin_dt;
-  auto total = [&](int q) {
-    const bool is_max = (q == PS_UMAX || q == PS_VMAX);
-    double x = sm[q * NW];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) x = is_max ? fmax(x, sm[q * NW + w]) : (x + sm[q * NW + w]);
-    return x;
-  };
-  if (t < PS_N + 2) {
-    const double x = total(t);
-    fin_r[t] = x;
-    fin_sqrt[t] = (t < PS_RP2 + 1) ? sqrt(x) : 0.0;     // DU2, DV2, U02, V02, RU2, RV2, RP2
-  } else if (t == 64 && crit) {
-    fin_dt = next_dt(total(PS_UMAX), total(PS_VMAX), a);
-  }
-  __syncthreads();
-  if (t == 0) {
-    double r[PS_N + 2];
-#pragma unroll
-    for (int q = 0; q < PS_N + 2; ++q) r[q] = fin_r[q];
-    if (flush) {
-      if (writer) {
-        double* rec = a.rec + (size_t)((iter - 1) % a.rec_cap) * LDC_REC_LEN;
-        rec[LDC_REC_Z] = 0.5 * r[PS_N];
-        rec[LDC_REC_P] = 0.5 * r[PS_N + 1];
-      }
-      if (PERSIST) S->flushed = iter; else a.ctrl[LDC_CTRL_FLUSHED] = iter;
-    }
-    if (crit) {
-      const double relu = fin_sqrt[PS_DU2] / (fin_sqrt[PS_U02] + 1e-12);
-      const double relv = fin_sqrt[PS_DV2] / (fin_sqrt[PS_V02] + 1e-12);
-      // Python's max(a, b) returns a unless b > a: a NaN in relv is dropped, one in relu sticks
-      const double rel = (relv > relu) ? relv : relu;
-      if (writer) {
-        double* rec = a.rec + (size_t)(iter % a.rec_cap) * LDC_REC_LEN;   // `iter` = 0-based index of this iteration
-        rec[LDC_REC_REL] = rel;
-        rec[LDC_REC_RU] = fin_sqrt[PS_RU2];
-        rec[LDC_REC_RV] = fin_sqrt[PS_RV2];
-        rec[LDC_REC_RP] = fin_sqrt[PS_RP2];
-        rec[LDC_REC_E] = 0.5 * r[PS_E];
-        rec[LDC_REC_Z] = 0.0;
-        rec[LDC_REC_P] = 0.0;
-        rec[LDC_REC_DT] = PERSIST ? S->dt : a.scal[LDC_SCAL_DT];
-      }
-      const int latch = (iter >= a.warmup && rel < a.tol) ? 1
-                        : (a.nan_guard && !(fabs(rel) <= 1.79769313486231570815e308)) ? 2 : 0;
+  if (t < 64) {
+    const FinOut o = fin_decide_wave(a, sm, t, crit, flush, iter, flushed, PERSIST ? S->dt : sload(a.scal + LDC_SCAL_DT),
+                                     writer);
+    if (t == 0) {
       if (PERSIST) {
-        S->umax = r[PS_UMAX]; S->vmax = r[PS_VMAX]; S->dt = fin_dt;
-        S->iter = iter + 1;
-        if (!a.with_diag) S->flushed = iter + 1;
-        if (latch) S->done = latch;
+        S->flushed = o.flushed;
+        if (crit) {
+          S->umax = o.umax; S->vmax = o.vmax; S->dt = o.dt; S->iter = o.iter;
+          if (o.latch) S->done = o.latch;
+        }
       } else {
-        a.scal[LDC_SCAL_UMAX] = r[PS_UMAX];
-        a.scal[LDC_SCAL_VMAX] = r[PS_VMAX];
-        a.scal[LDC_SCAL_DT] = fin_dt;
-        a.ctrl[LDC_CTRL_ITER] = iter + 1;
-        if (!a.with_diag) a.ctrl[LDC_CTRL_FLUSHED] = iter + 1;      // nothing to fold for this record
-        if (latch) a.ctrl[LDC_CTRL_DONE] = latch;
+        fin_publish(a, o, crit, flush);
       }
     }
   }
@@ -1088,7 +1172,12 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int M = a.M, LD = a.LD, T = a.T, nt = T * T, m1 = M - 1;
   int b = (int)blockIdx.x;
-  if (b == a.fin_block) { fin_work<false>(a.fin, red, tid, nullptr, true); return; }
+  // The finalize block closes the iteration: change norms, |R|, E, next dt, latch, record.  It is the longest block of
+  // the launch (a cold round trip for the partial sums, twelve wave reductions, the square roots): block 0, first out.
+  if (a.fin_block >= 0) {
+    if (b == 0) { fin_work<false>(a.fin, red, tid, nullptr, true); return; }
+    b -= 1;
+  }
   // T tiles: the operand fragments of this wave's first four k-groups go out BEFORE the gate below (harmless
   // reads); behind it every thread used to sit through a cold miss for two control words and a barrier before its
   // first load, and then through one exposed load latency per group (-0.6 us per iteration at N=64, neutral at 256).
@@ -1105,21 +1194,14 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
       fI[u] = ldpk(a.IyFK, a.NB, J, g, lane); fG[u] = ldpk(a.GyFK, a.NB, J, g, lane);
     }
   }
-  // After the latch nothing changes any more: once the last record is flushed every tile of
-  // this launch would reproduce bit-identical output, so the whole launch may be skipped.
-  // (Blocks may disagree while the finalize block of this very launch flips FLUSHED; that
-  // is benign for the same reason.)
-  // The decision must be uniform over the work-group (there are barriers below) although the
-  // flags can flip while this launch runs: ONE thread reads them, everyone uses its answer.
-  __shared__ int gate[2];
-  if (tid == 0) {
-    const int st0 = a.ctrl[LDC_CTRL_STEP];
-    gate[0] = st0;
-    gate[1] = (!a.ungated && a.ctrl[LDC_CTRL_DONE] != 0 && a.ctrl[LDC_CTRL_FLUSHED] >= st0) ? 1 : 0;
-  }
-  __syncthreads();
-  const int step = gate[0];
-  if (gate[1]) return;
+  // A post launch behind a latched (no-op) stage 4 has nothing new to transform: its tiles would reproduce what
+  // is there bit for bit, so they leave.  The word they look at, ctrl[LIVE], is written by that stage-4 launch --
+  // complete before this one starts -- and by nobody in THIS launch: the finalize block next door flips DONE,
+  // ITER and FLUSHED while the tiles run, and a gate on those could see them change under it.
+  // Every wave reads the two words itself, by scalar loads issued with the prefetch above: the same values for all
+  // (a block-uniform decision, there are barriers below) and no cold miss, LDS hop and barrier in front of the MFMAs.
+  const int step = sload(a.ctrl + LDC_CTRL_STEP);
+  if (!a.ungated && sload(a.ctrl + LDC_CTRL_LIVE) == 0) return;
   double* partZ = a.partZ0 + (size_t)((step > 0 ? step - 1 : 0) & 1) * a.stride;
 
   if (t_tile) {
@@ -1159,12 +1241,13 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
     const bool ok = (c0 + tr < M) && (r0 + tc < M);
     st_out(a.T1T + o, ok ? t1[tc * 17 + tr] : 0.0, a.wt);
     st_out(a.T2T + o, ok ? t2[tc * 17 + tr] : 0.0, a.wt);
-    {   // packed twins: block (J, I) of T1T / T2T, thread t stores double t (row pr, column pc of the block)
-      const int pl = tid >> 2, pr = pl & 15, pc = 4 * (pl >> 4) + (tid & 3);
-      const size_t kbT = ((size_t)(J * a.NB + I) << 8) + tid;
-      const bool okp = (c0 + pr < M) && (r0 + pc < M);
-      st_out(a.T1TK + kbT, okp ? t1[pc * 17 + pr] : 0.0, a.wt);
-      st_out(a.T2TK + kbT, okp ? t2[pc * 17 + pr] : 0.0, a.wt);
+    {   // packed twins: block (J, I) of T1T / T2T, 16 bytes per store: threads 0..127 T1T, 128..255 T2T; thread h of
+        // a half stores doubles 2h, 2h+1 of the 2-KB block = elements (row pr, columns pc, pc+1), like the stage kernel
+      const int hh = tid & 127, pl = hh >> 1, pr = pl & 15, pc = 4 * (pl >> 4) + 2 * (hh & 1);
+      const size_t kbT = ((size_t)(J * a.NB + I) << 8) + 2 * hh;
+      const bool ok0 = (c0 + pr < M) && (r0 + pc < M), ok1 = (c0 + pr < M) && (r0 + pc + 1 < M);
+      const double* tt = tid < 128 ? t1 : t2;
+      st_out2((tid < 128 ? a.T1TK : a.T2TK) + kbT, ok0 ? tt[pc * 17 + pr] : 0.0, ok1 ? tt[(pc + 1) * 17 + pr] : 0.0, a.wt);
     }
     return;
   }
@@ -1175,8 +1258,8 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
     const int k = b * kWaves + wv;
     if (k < M) {
       const double* pk = a.P + (size_t)k * LD;
-      const double t1 = dot_rows(pk, a.IyF + (size_t)m1 * LD, M, lane);
-      const double t2 = dot_rows(pk, a.GyF + (size_t)m1 * LD, M, lane);
+      double t1, t2;
+      dot_rows2<false>(pk, a.IyF + (size_t)m1 * LD, a.GyF + (size_t)m1 * LD, M, lane, t1, t2);
       if (lane == 0) { st_out(a.T1T + (size_t)m1 * LD + k, t1, a.wt); st_out(a.T2T + (size_t)m1 * LD + k, t2, a.wt); }
     }
     return;
@@ -1299,13 +1382,6 @@ __device__ __forceinline__ bool grid_sync(unsigned* sync, unsigned& phase, unsig
   return S->abort == 0;
 }
 
-// wave-cooperative dot product, `a` written by other work-groups in this launch
-__device__ __forceinline__ double dot_rows_coh(const double* a, const double* b, int n, int lane) {
-  double s = 0.0;
-  for (int k = lane; k < n; k += 64) s = nm_madd(gl_t<true>(a, (size_t)k), b[k], s);
-  return wave_sum(s);
-}
-
 // T1T / T2T of the pressure array P (packed twin PK) as a phase of the persistent kernel: tile (I, J) by waves 0-3
 // with the K split, the order of the sums and the stores of post_kernel's T tiles; the rows of index M-1 (tail) by
 // waves 4-7, one wave per k like post_kernel's edge blocks.  All kStageThreads threads call.
@@ -1335,8 +1411,8 @@ __device__ __forceinline__ void post_phase(const PostArgs& a, const double* P, c
   } else if (a.tail) {
     for (int k = bx * kWaves + (wv - kWaves); k < M; k += nblk * kWaves) {
       const double* pk = P + (size_t)k * LD;
-      const double t1 = dot_rows_coh(pk, a.IyF + (size_t)m1 * LD, M, lane);
-      const double t2 = dot_rows_coh(pk, a.GyF + (size_t)m1 * LD, M, lane);
+      double t1, t2;
+      dot_rows2<true>(pk, a.IyF + (size_t)m1 * LD, a.GyF + (size_t)m1 * LD, M, lane, t1, t2);
       if (lane == 0) { st_out(a.T1T + (size_t)m1 * LD + k, t1, 1); st_out(a.T2T + (size_t)m1 * LD + k, t2, 1); }
     }
   }
@@ -1875,6 +1951,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void trial_kernel(const TrialArgs
     const FinalArgs fa = LDC_TRIAL_ARG(FinalArgs, post.fin);
     fa.ctrl[LDC_CTRL_DONE] = S.done; fa.ctrl[LDC_CTRL_ITER] = S.iter; fa.ctrl[LDC_CTRL_STEP] = S.step;
     fa.ctrl[LDC_CTRL_FLUSHED] = S.flushed; fa.ctrl[LDC_CTRL_PDONE] = S.pdone; fa.ctrl[LDC_CTRL_DROWS] = S.drows;
+    fa.ctrl[LDC_CTRL_LIVE] = 0;                  // every iteration of this launch has been closed in it
     fa.scal[LDC_SCAL_DT] = S.dt; fa.scal[LDC_SCAL_UMAX] = S.umax; fa.scal[LDC_SCAL_VMAX] = S.vmax;
   }
 }
@@ -2205,7 +2282,7 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
   a.stride = p.partials_stride;
   a.ablate = s->stamps ? s->ablate : (s->ablate & ~64);
   a.wt = write_through_policy(s, s->nt);
-  a.rm_out = (k == 3) ? 1 : 0;
+  a.rm_out = (k == 3 && !(s->ablate & 16384)) ? 1 : 0;      // (16384: timing, stage 4 without its row-major velocity stores)
   a.dump[0] = s->stamps;
   // ping-pong: 0: S0 -> A, 1: A -> B, 2: B -> A, 3: A -> S0 (in place)
   const double *in[4][4] = {{p.U, p.UT, p.V, p.VT}, {p.UA, p.UAT, p.VA, p.VAT},
@@ -2319,9 +2396,10 @@ PostArgs make_post_args(const ldc_solver* s, const double* P, int do_omega, int 
   int grid = s->nt + s->n_pedge_blocks;
   if (do_omega) grid += s->nt + s->n_edge_blocks;
   a.fin_block = -1;
+  a.fin = make_final_args(s, with_diag, 1);       // (the persistent kernel takes its finalize arguments from here too)
   if (loop) {
-    a.fin_block = grid++;
-    a.fin = make_final_args(s, with_diag, 1);
+    a.fin_block = 0;            // one more block, in FRONT: the finalize block is the longest of the launch
+    ++grid;
   }
   *grid_out = grid;
   return a;

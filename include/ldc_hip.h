@@ -72,6 +72,8 @@ enum {
   LDC_CTRL_FLUSHED   = 3, /* records whose Z/P slots have been folded                   */
   LDC_CTRL_PDONE     = 4, /* state index whose Z/P partial sums are complete            */
   LDC_CTRL_DROWS     = 5, /* rows of those partial-sum slabs                            */
+  LDC_CTRL_LIVE      = 6, /* 1 when the last stage-4 launch updated the state (0: it was latched, the post launch
+                             behind it has nothing to transform)                        */
   LDC_CTRL_LEN       = 8
 };
 
