@@ -1162,6 +1162,8 @@ struct PostArgs {
   int NB, wt;
   const double *PK, *IyFK, *GyFK;   // packed twins read by the T tiles
   double *T1TK, *T2TK;              // packed twins they keep in step
+  const double *DxK, *DyK, *UK, *VTK;   // packed twins read by the omega tiles (stand-alone form)
+  double *WK, *WTK;                     // packed twins of omega they keep in step (the palinstrophy kernel reads them)
   FinalArgs fin;
 };
 
@@ -1272,10 +1274,9 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
     tile_of_block(b, T, I, J);
     const int r0 = 16 * I, c0 = 16 * J;
     v4d acc[2] = {(v4d){0, 0, 0, 0}, (v4d){0, 0, 0, 0}};
-    for (int g = wv; g < T; g += kWaves) {
-      const int k0 = 16 * g;
-      const v4d fDx = ldfrag(a.Dx, LD, r0, k0, lane), fVT = ldfrag(a.VT, LD, c0, k0, lane);
-      const v4d fU = ldfrag(a.U, LD, r0, k0, lane), fDy = ldfrag(a.Dy, LD, c0, k0, lane);
+    for (int g = wv; g < T; g += kWaves) {      // operands from the packed twins, like every MFMA of the loop
+      const v4d fDx = ldpk(a.DxK, a.NB, I, g, lane), fVT = ldpk(a.VTK, a.NB, J, g, lane);
+      const v4d fU = ldpk(a.UK, a.NB, I, g, lane), fDy = ldpk(a.DyK, a.NB, J, g, lane);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         acc[0] = MFMA_F64(fDx[s], fVT[s], acc[0]);
@@ -1300,6 +1301,11 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
     __syncthreads();
     const int tr = tid >> 4, tc = tid & 15;
     a.WT[(size_t)(c0 + tr) * LD + r0 + tc] = tw[tc * 17 + tr];
+    {   // packed twins of this tile: block (I, J) of omega, block (J, I) of its transposed copy (thread t = double t)
+      const int pl = tid >> 2, pr = pl & 15, pc = 4 * (pl >> 4) + (tid & 3);
+      a.WK[((size_t)(I * a.NB + J) << 8) + tid] = tw[pr * 17 + pc];
+      a.WTK[((size_t)(J * a.NB + I) << 8) + tid] = tw[pc * 17 + pr];
+    }
     double sums[1] = {valid ? a.wx[i] * a.wy[j] * w * w : 0.0};
     double dummy[1] = {0.0};
     block_reduce_store<1, 0>(sums, dummy, red + 16 * 17, partZ + (size_t)b * LDC_NPART, lane, wv);
@@ -1966,6 +1972,8 @@ struct PalinArgs {
   double* partP0;
   long long stride;
   int ungated;
+  int NB;
+  const double *DxK, *DyK, *WK, *WTK;      // packed twins: the operands of the tiles
 };
 
 template <bool BATCH>
@@ -1993,9 +2001,8 @@ __global__ __launch_bounds__(kThreads) void palin_kernel(const PalinArgs a_val, 
     const int r0 = 16 * I, c0 = 16 * J;
     v4d acc[2] = {(v4d){0, 0, 0, 0}, (v4d){0, 0, 0, 0}};
     for (int g = wv; g < T; g += kWaves) {
-      const int k0 = 16 * g;
-      const v4d fDx = ldfrag(a.Dx, LD, r0, k0, lane), fWT = ldfrag(a.WT, LD, c0, k0, lane);
-      const v4d fW = ldfrag(a.W, LD, r0, k0, lane), fDy = ldfrag(a.Dy, LD, c0, k0, lane);
+      const v4d fDx = ldpk(a.DxK, a.NB, I, g, lane), fWT = ldpk(a.WTK, a.NB, J, g, lane);
+      const v4d fW = ldpk(a.WK, a.NB, I, g, lane), fDy = ldpk(a.DyK, a.NB, J, g, lane);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         acc[0] = MFMA_F64(fDx[s], fWT[s], acc[0]);
@@ -2390,6 +2397,7 @@ PostArgs make_post_args(const ldc_solver* s, const double* P, int do_omega, int 
   a.wt = write_through_policy(s, s->nt);
   a.PK = (P == p.PA) ? p.PAK : (P == p.PB) ? p.PBK : p.PK;
   a.IyFK = p.IyFK; a.GyFK = p.GyFK; a.T1TK = p.T1TK; a.T2TK = p.T2TK;
+  a.DxK = p.DxK; a.DyK = p.DyK; a.UK = p.UK; a.VTK = p.VTK; a.WK = p.WK; a.WTK = p.WTK;
   a.T1T = p.T1T; a.T2T = p.T2T; a.W = p.W; a.WT = p.WT; a.wx = p.wx; a.wy = p.wy;
   a.ctrl = p.ctrl; a.partZ0 = p.partials + p.partials_stride; a.stride = p.partials_stride;
   a.ungated = loop ? 0 : 1;
@@ -2420,6 +2428,8 @@ PalinArgs make_palin_args(const ldc_solver* s, int loop) {
   a.Dx = p.Dx; a.Dy = p.Dy; a.W = p.W; a.WT = p.WT; a.wx = p.wx; a.wy = p.wy;
   a.ctrl = p.ctrl; a.partP0 = p.partials + 3 * p.partials_stride; a.stride = p.partials_stride;
   a.ungated = loop ? 0 : 1;
+  a.NB = p.LD / 16;
+  a.DxK = p.DxK; a.DyK = p.DyK; a.WK = p.WK; a.WTK = p.WTK;
   return a;
 }
 

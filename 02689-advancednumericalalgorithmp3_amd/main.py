@@ -173,9 +173,39 @@ def _mlflow_log(cfg, rec, solver):
     T.log_child_run(mlflow, cfg, rec, parent_id=_parent_of(cfg), time_series_batch=_ts_batch(solver))
 
 
+def hydra_main(argv: list) -> float | None:
+    """The reference's own launch path, for machines where Hydra (and its joblib / Optuna plugins, MLflow) are
+    installed: ``@hydra.main`` composes ``conf/`` exactly as the reference's ``main.py:228-252`` does, Hydra's
+    launcher / sweeper run one job per trial, ``utilities.mlflow.callback.MLflowSweepCallback`` keeps the parent
+    runs, and each job is ``run_solver`` below -- same solver plugin, same records.  (Trials do not share launches
+    on this path: Hydra starts one process per job.  The built-in launcher above is what batches them.)"""
+    import hydra
+    from hydra.core.hydra_config import HydraConfig
+    from omegaconf import OmegaConf
+
+    @hydra.main(config_path=str(HERE / "conf"), config_name="config", version_base=None)
+    def _job(cfg):
+        plain = OmegaConf.to_container(cfg, resolve=True)
+        try:
+            out_dir = Path(HydraConfig.get().runtime.output_dir)
+        except Exception:                                   # outside a Hydra job (tests with a stand-in)
+            out_dir = Path("hydra_outputs/run")
+        rec = run_solver(plain, out_dir)
+        return rec["objective"]                             # the Optuna sweeper minimises the job's return value
+
+    saved = sys.argv
+    sys.argv = [saved[0]] + list(argv)
+    try:
+        return _job()
+    finally:
+        sys.argv = saved
+
+
 def main(argv=None) -> float | None:
     argv = list(sys.argv[1:] if argv is None else argv)
     logging.basicConfig(level=logging.INFO, format="[%(asctime)s][%(name)s] %(message)s")
+    if "--hydra" in argv or os.environ.get("LDC_LAUNCHER", "").lower() == "hydra":
+        return hydra_main([a for a in argv if a != "--hydra"])
     multirun_flag = False
     conf_dir = HERE / "conf"
     overrides = []

@@ -310,7 +310,7 @@ def main():
 
     farm = None
     if not a.no_farm:
-        fN, fB = 128, 4                       # config 5's trial shape: N = 128, four trials fill the 256 CUs
+        fN, fB = 128, 8                       # config 5's shape: N = 128, 64 trials over 8 GPUs = 8 per GPU and round
         rate, n_it = farm_rate(fN, fB, f"cuda:{local}", dist)
         rates = dist.all_gather_object(rate)
         farm = {"value": float(sum(rates)), "unit": "trial-iterations/s", "n_gpus": world, "trials_per_gpu": fB, "N": fN,

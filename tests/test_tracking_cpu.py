@@ -250,3 +250,61 @@ def test_abi_calls_run_on_the_solvers_own_device(monkeypatch):
     for mod in (sg_mod, fsg_mod):
         src = inspect.getsource(mod)
         assert "L.stream_ptr()" not in src
+
+
+def test_real_hydra_path_is_wired_when_hydra_is_importable(fake_mlflow, monkeypatch, tmp_path):
+    """``main.py --hydra`` hands the job to ``@hydra.main`` and the reference's callback target resolves
+    (``utilities.mlflow.callback.MLflowSweepCallback``): checked with stand-in ``hydra`` / ``omegaconf`` modules
+    (neither package is installed here) -- the decorator receives conf/ + "config", the job function turns the
+    DictConfig into plain containers and runs ``run_solver``, its return value is the objective."""
+    import importlib.util
+    from conftest import PKG
+    seen = {}
+
+    class DictConfig(dict):
+        pass
+
+    omegaconf = types.ModuleType("omegaconf")
+    omegaconf.OmegaConf = types.SimpleNamespace(to_container=lambda cfg, resolve=True: dict(cfg))
+    omegaconf.DictConfig = DictConfig
+    hydra = types.ModuleType("hydra")
+
+    def hydra_main(config_path=None, config_name=None, version_base=None):
+        seen.update(config_path=config_path, config_name=config_name)
+
+        def deco(fn):
+            def run():
+                seen["argv"] = list(sys.argv[1:])
+                return fn(DictConfig(N=16, Re=100, solver=dict(name="spectral"), sweep_name="s", experiment_name="e"))
+            return run
+        return deco
+
+    hydra.main = hydra_main
+    core = types.ModuleType("hydra.core")
+    hc = types.ModuleType("hydra.core.hydra_config")
+    hc.HydraConfig = types.SimpleNamespace(get=lambda: types.SimpleNamespace(runtime=types.SimpleNamespace(output_dir=str(tmp_path))))
+    exp = types.ModuleType("hydra.experimental")
+    cb = types.ModuleType("hydra.experimental.callback")
+    cb.Callback = type("Callback", (), {})
+    for name, mod in (("hydra", hydra), ("hydra.core", core), ("hydra.core.hydra_config", hc), ("omegaconf", omegaconf),
+                      ("hydra.experimental", exp), ("hydra.experimental.callback", cb)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    monkeypatch.delitem(sys.modules, "utilities.mlflow.callback", raising=False)
+    spec = importlib.util.spec_from_file_location("ldc_main_hydra", PKG / "main.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(mod, "run_solver", lambda cfg, out_dir, device=None: seen.update(cfg=cfg, out=out_dir) or {"objective": 0.25})
+    assert mod.main(["--hydra", "solver=spectral", "N=16"]) == 0.25
+    assert seen["config_name"] == "config" and seen["config_path"].endswith("conf")
+    assert seen["argv"] == ["solver=spectral", "N=16"] and type(seen["cfg"]) is dict and seen["cfg"]["N"] == 16
+    assert str(seen["out"]) == str(tmp_path)
+    # the callback of the reference's config resolves and drives the same tracker
+    from utilities.mlflow.callback import MLflowSweepCallback
+    c = MLflowSweepCallback()
+    cfg = DictConfig(experiment_name="E", sweep_name="hs", Re=100, mlflow=dict(mode="files", tracking_uri="./mlruns"))
+    c.on_multirun_start(cfg)
+    c.on_job_start(cfg)
+    pid = os.environ["MLFLOW_PARENT_RUN_ID"]
+    assert fake_mlflow.runs[pid]["name"] == "hs" and fake_mlflow.runs[pid]["tags"]["sweep"] == "parent"
+    c.on_multirun_end(cfg)
+    assert "MLFLOW_PARENT_RUN_ID" not in os.environ
