@@ -225,7 +225,10 @@ def main(argv=None) -> float | None:
     space, fixed = C.sweep_space(base_cfg, cli_values, multirun)
     search = {k: v for k, v in space.items() if isinstance(v, C.Interval)}
     dist = Dist().init()
-    device = f"cuda:{dist.local_rank}" if dist.world > 1 else None
+    device = None
+    if dist.world > 1:          # one GPU per rank; ranks beyond the visible cards share them (tests: 2 ranks, 1 card)
+        import torch
+        device = f"cuda:{dist.local_rank % max(1, torch.cuda.device_count())}"
 
     stamp_cfg = C.resolve(C.compose_job(composer, overrides, fixed))
     hy = stamp_cfg.get("hydra", {})

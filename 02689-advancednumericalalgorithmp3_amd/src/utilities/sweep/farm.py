@@ -51,7 +51,9 @@ class Dist:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # LDC_DIST_BACKEND=gloo: several ranks on ONE card (RCCL wants a GPU per rank) -- the farm gathers
+                # host objects only, so gloo carries it just as well; used by the two-rank GPU test
+                backend = os.environ.get("LDC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             kw = {}
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
