@@ -16,6 +16,12 @@
 //   d/dx  (Dx @ U)[i][j]   = sum_k Dx[i][k] * UT[j][k]
 //   d/dy  (U @ Dy^T)[i][j] = sum_k U [i][k] * Dy[j][k]
 //
+// Two forms of the iteration loop share the arithmetic (K split, order of every sum, the epilogue's explicit FMAs):
+//   launch per RK stage  stage_kernel x 4 + post_kernel (finalize block first, pressure transforms), hipGraph replays;
+//                        the product path at every size
+//   persistent           trial_kernel: all iterations of a chunk in ONE launch, work-groups keep their tile's state in
+//                        registers, a counter barrier per stage; bit-identical, opt-in, measured slower
+//
 // MFMA lane maps (v_mfma_f64_16x16x4_f64; pinned by tests/test_gpu_parity.py::test_mfma_lane_maps):
 //   A: lane l holds A[row l&15][k l>>4]      B: lane l holds B[k l>>4][col l&15]
 //   D: lane l, reg r holds D[row (l>>4)+4r][col l&15]

@@ -106,3 +106,16 @@ def test_persistent_mode_switch_and_limits():
     big._begin(0.0)
     assert L.lib().ldc_solver_set_persistent(big._handle, 1) == -1
     big.close()
+
+
+@pytest.mark.parametrize("kw", [dict(Lx=2.0, Ly=1.0, lid_velocity=1.5), dict(corner_treatment="saad"),
+                                dict(basis_type="legendre"), dict(CFL=0.8, beta_squared=2.0, corner_smoothing=0.05)],
+                         ids=["rect", "saad", "legendre", "cfl"])
+def test_persistent_variants_bit_identical(kw):
+    """Non-default parameters of the reference's constructor (rectangular cavity, Saad lid, Legendre basis, other
+    CFL / beta^2): the persistent kernel and the launch path agree bit for bit there too."""
+    a = _run(48, 100.0, 200, 1, True, **kw)
+    b = _run(48, 100.0, 200, 0, True, **kw)
+    for x, y, name in zip(a, b, ("records", "u", "v", "p")):
+        assert np.array_equal(x, y), name
+    assert np.all(np.isfinite(a[0]))
