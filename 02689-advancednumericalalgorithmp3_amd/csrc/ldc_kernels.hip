@@ -344,7 +344,7 @@ enum { PS_DU2 = 0, PS_DV2, PS_U02, PS_V02, PS_RU2, PS_RV2, PS_RP2, PS_E, PS_NSUM
 static_assert(PS_N <= LDC_NPART, "partials row too small");
 static_assert(PS_NSUM == 8, "stage-4 reduction assigns one wave per sum");
 
-// What ONE wave makes of the wave totals sm[q * 4 + w] (q < PS_N + 2 values, w < 4 waves): cross-wave totals, their
+// What ONE wave makes of the totals tot[q] (q < PS_N + 2 values): their
 // square roots and the next dt by SEPARATE lanes in parallel (eight fp64 square roots, the divisions and next_dt in a
 // row on one lane were most of the finalize block's tail), everything else uniformly on every lane through
 // readlane.  `writer`: lane 0 also stores the record, the control words and the scalars.  Results are uniform over
@@ -358,14 +358,7 @@ struct FinOut {
 __device__ __forceinline__ FinOut fin_decide_wave(const FinalArgs& a, const double* sm, const int lane, const bool crit,
                                                   const bool flush, const int iter, const int flushed,
                                                   const double dt_cur, const bool writer) {
-  constexpr int NW = kThreads / 64;
-  auto total = [&](int q) {
-    const bool is_max = (q == PS_UMAX || q == PS_VMAX);
-    double x = sm[q * NW];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) x = is_max ? fmax(x, sm[q * NW + w]) : (x + sm[q * NW + w]);
-    return x;
-  };
+  auto total = [&](int q) { return sm[q]; };
   double xr = 0.0, xs = 0.0;
   if (lane < PS_N + 2) {
     xr = total(lane);
@@ -1084,10 +1077,11 @@ __device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t, 
     for (int q = 0; q < PS_N; ++q) pre[q] = gl(p, q);
   }
   if (!flush && !crit) return;
-  // Rows r >= number of rows contribute the neutral 0.0, so with at most 64 rows only wave 0 has anything to load and
-  // to reduce; the other waves' totals are exactly the 0.0 they would have computed.
-  const bool one_wave = PERSIST && a.nblk4 <= 64 && drows <= 64;
-  const bool active = t < (one_wave ? 64 : kThreads);
+  // The fold, in ONE fixed order whoever runs it: thread t sums rows t, t + 256, ...; the 256 x 12 values cross LDS
+  // ([value][thread]); wave w takes values 3w .. 3w+2, lane l adds the four entries l, l+64, l+128, l+192 and ONE DPP
+  // tree per value finishes it.  (Twelve trees in each of the four waves, the form before, were 1 200 cycles of the
+  // finalize block's critical path; this is three per wave.)
+  const bool active = t < kThreads;
   double v[PS_N + 2];
 #pragma unroll
   for (int q = 0; q < PS_N + 2; ++q) v[q] = 0.0;
@@ -1115,22 +1109,30 @@ __device__ __forceinline__ void fin_work(const FinalArgs& a, double* sm, int t, 
     for (int r = t; r < drows; r += kThreads) v[PS_N] += gl_t<PERSIST>(pz, (size_t)r * LDC_NPART);
     for (int r = t; r < drows; r += kThreads) v[PS_N + 1] += gl_t<PERSIST>(pp, (size_t)r * LDC_NPART);
   }
-  // wave totals on DPP moves, then one value per wave through LDS (fixed order)
-  constexpr int NW = kThreads / 64;
+  static_assert((PS_N + 2) % kWaves == 0, "the fold deals its values evenly over the four waves");
+  __shared__ double fin_tot[PS_N + 2 + 2];
   if (active) {
 #pragma unroll
-    for (int q = 0; q < PS_N + 2; ++q) {
-      const bool is_max = (q == PS_UMAX || q == PS_VMAX);
-      v[q] = is_max ? wave_max(v[q]) : wave_sum(v[q]);
-      if ((t & 63) == 0) sm[q * NW + (t >> 6)] = v[q];
-    }
-  } else if (one_wave && t < kThreads && (t & 63) == 0) {
+    for (int q = 0; q < PS_N + 2; ++q) sm[q * kThreads + t] = v[q];
+  }
+  __syncthreads();
+  if (active) {
+    const int w = t >> 6, l = t & 63;
 #pragma unroll
-    for (int q = 0; q < PS_N + 2; ++q) sm[q * NW + (t >> 6)] = 0.0;
+    for (int k = 0; k < (PS_N + 2) / 4; ++k) {
+      const int q = w * ((PS_N + 2) / 4) + k;
+      const bool is_max = (q == PS_UMAX || q == PS_VMAX);
+      const double* b = sm + q * kThreads + l;
+      double x;
+      if (is_max) x = fmax(fmax(fmax(b[0], b[64]), b[128]), b[192]);
+      else x = ((b[0] + b[64]) + b[128]) + b[192];
+      x = is_max ? wave_max(x) : wave_sum(x);
+      if (l == 0) fin_tot[q] = x;
+    }
   }
   __syncthreads();
   if (t < 64) {
-    const FinOut o = fin_decide_wave(a, sm, t, crit, flush, iter, flushed, PERSIST ? S->dt : sload(a.scal + LDC_SCAL_DT),
+    const FinOut o = fin_decide_wave(a, fin_tot, t, crit, flush, iter, flushed, PERSIST ? S->dt : sload(a.scal + LDC_SCAL_DT),
                                      writer);
     if (t == 0) {
       if (PERSIST) {
