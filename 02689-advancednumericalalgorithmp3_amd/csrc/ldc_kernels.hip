@@ -1366,6 +1366,8 @@ struct TrialArgs {
   const double* Pst[3];          // smoother mode: the stage pressure whose transforms follow stage 1, 2, 3 (PA, PB, PA)
   const double* PstK[3];
   int n_iters;
+  int local;                     // one-XCD placement (mode 2): tiles are claimed by the work-groups of ONE XCD, see trial_kernel
+  int nt;                        // work-groups that carry a tile (T * T); the launch may be larger (local)
   unsigned* sync;                // [0] arrival counter, [LDC_SYNC_GIVEUP] set when a spin gave up; zeroed before the launch
   double* stamps;                // timing experiments (ldc_debug_stamps): 64 doubles per work-group, or null
 };
@@ -1376,21 +1378,44 @@ constexpr unsigned long long kSpinLimitTicks = 200000000ull;    // 2 s of the 10
 // Barrier among the `nwg` work-groups of this launch; `phase` counts the barriers passed (monotonic counter: no reset,
 // no generation flip).  Returns false when the wait was given up (a peer is not resident or has left): every thread
 // of the work-group sees the same answer and the kernel ends.
-__device__ __forceinline__ bool grid_sync(unsigned* sync, unsigned& phase, unsigned nwg, int tid, TrialState* S) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have left
+__device__ __forceinline__ bool grid_sync(unsigned* sync, unsigned& phase, unsigned nwg, int tid, TrialState* S,
+                                          const bool local) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have left (write-through: the chip; local: the L2)
   __syncthreads();
   ++phase;
   if (tid == 0) {
     LDC_GLOBAL unsigned* ctr = (LDC_GLOBAL unsigned*)sync;
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned target = phase * nwg;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinLimitTicks) {
-        S->abort = 1;
-        __hip_atomic_store(ctr + LDC_SYNC_GIVEUP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
+    if (local) {
+      // every participant sits on ONE XCD: the counter lives in that XCD's L2 -- adds and polls are L2 atomics
+      // without sc1 (an sc1 atomic is executed behind the fabric and drops the line from the L2)
+      // (the poll is a returning atomic OR of zero written in asm: as a builtin hipcc turns an idempotent
+      //  read-modify-write into a plain load, which the CU's L1 would serve -- stale for ever)
+      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      auto peek = [&]() {
+        unsigned r;
+        const unsigned zero = 0u;
+        asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(ctr), "v"(zero) : "memory");
+        return r;
+      };
+      while (peek() < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinLimitTicks) {
+          S->abort = 1;
+          __hip_atomic_store(ctr + LDC_SYNC_GIVEUP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    } else {
+      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinLimitTicks) {
+          S->abort = 1;
+          __hip_atomic_store(ctr + LDC_SYNC_GIVEUP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
       }
     }
   }
@@ -1402,7 +1427,7 @@ __device__ __forceinline__ bool grid_sync(unsigned* sync, unsigned& phase, unsig
 // with the K split, the order of the sums and the stores of post_kernel's T tiles; the rows of index M-1 (tail) by
 // waves 4-7, one wave per k like post_kernel's edge blocks.  All kStageThreads threads call.
 __device__ __forceinline__ void post_phase(const PostArgs& a, const double* P, const double* PK, int bx, int nblk,
-                                           double* red, int tid) {
+                                           double* red, int tid, const int wt) {
   const int lane = tid & 63, wv = tid >> 6;
   const int M = a.M, LD = a.LD, T = a.T, m1 = M - 1;
   const bool tile_wave = wv < kWaves;
@@ -1429,7 +1454,7 @@ __device__ __forceinline__ void post_phase(const PostArgs& a, const double* P, c
       const double* pk = P + (size_t)k * LD;
       double t1, t2;
       dot_rows2<true>(pk, a.IyF + (size_t)m1 * LD, a.GyF + (size_t)m1 * LD, M, lane, t1, t2);
-      if (lane == 0) { st_out(a.T1T + (size_t)m1 * LD + k, t1, 1); st_out(a.T2T + (size_t)m1 * LD + k, t2, 1); }
+      if (lane == 0) { st_out(a.T1T + (size_t)m1 * LD + k, t1, wt); st_out(a.T2T + (size_t)m1 * LD + k, t2, wt); }
     }
   }
   __syncthreads();
@@ -1462,7 +1487,7 @@ __device__ __forceinline__ void post_phase(const PostArgs& a, const double* P, c
     const size_t kbT = ((size_t)(J * a.NB + I) << 8) + 2 * hh;
     const bool ok0 = (c0 + pr < M) && (r0 + pc < M), ok1 = (c0 + pr < M) && (r0 + pc + 1 < M);
     const double* tt = tid < 128 ? t1 : t2;
-    st_out2((tid < 128 ? a.T1TK : a.T2TK) + kbT, ok0 ? tt[pc * 17 + pr] : 0.0, ok1 ? tt[(pc + 1) * 17 + pr] : 0.0, 1);
+    st_out2((tid < 128 ? a.T1TK : a.T2TK) + kbT, ok0 ? tt[pc * 17 + pr] : 0.0, ok1 ? tt[(pc + 1) * 17 + pr] : 0.0, wt);
   }
 }
 
@@ -1502,6 +1527,7 @@ struct TileCtx {
   // tile and thread geometry
   int M, LD, T, NB, tail, m1, I, J, r0, c0;
   int tid, lane, wv, role, kq, ng;
+  int wt;                                // stores other work-groups read: 1 write-through (sc1), 0 plain (one-XCD placement)
   bool rowE, colE, cornE, anyE;          // block-uniform: which index-(M-1) job this tile carries
   bool owner, edge_thr, colnode;
   int ekind, eidx, i, j, ti, tj, tabi, tabj;
@@ -1745,7 +1771,7 @@ __device__ __forceinline__ void tile_stage(TileCtx& c, const StageArgs a, double
     if (DIAG == 1) {
       const double w = valid ? (vx - uy) : 0.0;
       if (owner) tw[ti * 17 + tj] = w;
-      else { st_out(a.W + ij, w, 1); st_out(a.WT + (size_t)j * LD + i, w, 1); }
+      else { st_out(a.W + ij, w, c.wt); st_out(a.WT + (size_t)j * LD + i, w, c.wt); }
       dsum = valid ? wq * w * w : 0.0;
     }
     if (DIAG == 2) {
@@ -1766,7 +1792,7 @@ __device__ __forceinline__ void tile_stage(TileCtx& c, const StageArgs a, double
       else if (i == 0 || i == M - 1 || j == 0) { un = 0.0; vn = 0.0; }
       if (has_p) {
         const double pn = interior ? nm_madd(adt, Rp, p0) : 0.0;
-        st_out(a.Pout + ij, pn, 1);        // row-major: the transforms' rows of index M-1 contract whole rows of p
+        st_out(a.Pout + ij, pn, c.wt);        // row-major: the transforms' rows of index M-1 contract whole rows of p
         tp[ti * 17 + tj] = pn;
         if (LAST) c.p0 = pn;
       }
@@ -1803,11 +1829,11 @@ __device__ __forceinline__ void tile_stage(TileCtx& c, const StageArgs a, double
     const size_t kb = ((size_t)(I * NB + J) << 8) + 2 * hh, kbT = ((size_t)(J * NB + I) << 8) + 2 * hh;
     const int e = pr * 17 + pc, eT = pc * 17 + pr;
     if (tid < 128) {
-      st_out2(a.UoutK + kb, tu[e], tu[e + 1], 1); st_out2(a.UoutTK + kbT, tu[eT], tu[eT + 17], 1);
-      if (DIAG == 1) { st_out2(a.WK + kb, tw[e], tw[e + 1], 1); st_out2(a.WTK + kbT, tw[eT], tw[eT + 17], 1); }
+      st_out2(a.UoutK + kb, tu[e], tu[e + 1], c.wt); st_out2(a.UoutTK + kbT, tu[eT], tu[eT + 17], c.wt);
+      if (DIAG == 1) { st_out2(a.WK + kb, tw[e], tw[e + 1], c.wt); st_out2(a.WTK + kbT, tw[eT], tw[eT + 17], c.wt); }
     } else {
-      st_out2(a.VoutK + kb, tv[e], tv[e + 1], 1); st_out2(a.VoutTK + kbT, tv[eT], tv[eT + 17], 1);
-      if (has_p) st_out2(a.PoutK + kb, tp[e], tp[e + 1], 1);
+      st_out2(a.VoutK + kb, tv[e], tv[e + 1], c.wt); st_out2(a.VoutTK + kbT, tv[eT], tv[eT + 17], c.wt);
+      if (has_p) st_out2(a.PoutK + kb, tp[e], tp[e + 1], c.wt);
     }
   }
   if (DIAG != 0) {
@@ -1819,7 +1845,7 @@ __device__ __forceinline__ void tile_stage(TileCtx& c, const StageArgs a, double
       for (int m = 0; m < kStageWaves; ++m) x += red[lane + 64 * m];
       x = wave_sum(x);
       double* slab = (DIAG == 1 ? a.partZ0 : a.partP0) + (size_t)((step0 > 0 ? step0 - 1 : 0) & 1) * a.stride;
-      if (lane == 0) st_out(slab + (size_t)bx * LDC_NPART, x, 1);
+      if (lane == 0) st_out(slab + (size_t)bx * LDC_NPART, x, c.wt);
     }
   }
   if (LAST) {
@@ -1834,14 +1860,14 @@ __device__ __forceinline__ void tile_stage(TileCtx& c, const StageArgs a, double
 #pragma unroll
       for (int m = 0; m < kStageWaves; ++m) x += red[wv * kStageThreads + lane + 64 * m];
       x = wave_sum(x);
-      if (lane == 0) st_out(dst + wv, x, 1);
+      if (lane == 0) st_out(dst + wv, x, c.wt);
     }
     if (wv < 2) {
       double x = 0.0;
 #pragma unroll
       for (int m = 0; m < kStageWaves; ++m) x = fmax(x, red[(PS_NSUM + wv) * kStageThreads + lane + 64 * m]);
       x = wave_max(x);
-      if (lane == 0) st_out(dst + PS_NSUM + wv, x, 1);
+      if (lane == 0) st_out(dst + PS_NSUM + wv, x, c.wt);
     }
   }
   LDC_PSTAMP(6);
@@ -1885,10 +1911,40 @@ __global__ __launch_bounds__(kStageThreads, 2) void trial_kernel(const TrialArgs
   static_assert(!(SP && DIAGV), "the smoother carries no diagnostics");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ TrialState S;
-  const int tid = threadIdx.x, bx = (int)blockIdx.x, nblk = (int)gridDim.x;
+  const int tid = threadIdx.x;
   kernarg_ptr kargs = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();     // TrialArgs is the only argument
   const int n_iters = LDC_TRIAL_ARG(int, n_iters);
   unsigned* const sync = LDC_TRIAL_ARG(unsigned*, sync);
+  const bool local = LDC_TRIAL_ARG(int, local) != 0;
+  const int nblk = LDC_TRIAL_ARG(int, nt);
+  int bx = (int)blockIdx.x;
+  if (local) {
+    // One-XCD placement.  The launch holds several times more work-groups than tiles; the hardware deals them over
+    // the XCDs.  The first work-group to get here elects ITS XCD (it reads the id from the hardware, nothing is
+    // assumed about which block lands where); work-groups that find themselves on that XCD claim the tiles in the
+    // order they arrive, every other work-group leaves at once.  All T*T claimants then share one L2: the state they
+    // exchange needs no write-through and no trip over the fabric (plain stores; L1-bypassing loads served by the
+    // L2; the barrier counter an L2 atomic).  Should fewer than T*T work-groups of the elected XCD show up, the
+    // first barrier gives up after its bounded wait and the launch ends with LDC_E_SYNC like any other lost peer.
+    __shared__ int claim;
+    if (tid == 0) {
+      const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15u;   // HW_REG_XCC_ID, 4 bits
+      LDC_GLOBAL unsigned* w = (LDC_GLOBAL unsigned*)sync;
+      unsigned expect = 0u;
+      const bool won = __hip_atomic_compare_exchange_strong(w + LDC_SYNC_XCC, &expect, xcc + 1u, __ATOMIC_RELAXED,
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned elected = won ? xcc + 1u : expect;
+      int mine = -1;
+      if (elected == xcc + 1u) {
+        const unsigned k = __hip_atomic_fetch_add(w + LDC_SYNC_HEAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k < (unsigned)nblk) mine = (int)k;
+      }
+      claim = mine;
+    }
+    __syncthreads();
+    bx = claim;
+    if (bx < 0) return;
+  }
   // timing experiments: cycle stamps (s_memtime) of the LAST iteration's phase boundaries, thread 0 of every work-group
   double* const stamps = LDC_TRIAL_ARG(double*, stamps);
 #define LDC_TSTAMP(k) do { if (stamps != nullptr && tid == 0 && it == n_iters - 1) \
@@ -1903,6 +1959,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void trial_kernel(const TrialArgs
     }
   }
   TileCtx c;
+  c.wt = local ? 0 : 1;
   tile_setup(c, LDC_TRIAL_ARG(StageArgs, st[0]), bx, lds);      // ends with a work-group barrier
   unsigned phase = 0;
   constexpr int D1 = DIAGV ? 1 : 0, D2 = DIAGV ? 2 : 0;
@@ -1911,7 +1968,7 @@ __global__ __launch_bounds__(kStageThreads, 2) void trial_kernel(const TrialArgs
     const PostArgs pq = LDC_TRIAL_ARG(PostArgs, post);
     const double* P = which < 0 ? pq.P : LDC_TRIAL_ARG(const double*, Pst[which < 0 ? 0 : which]);
     const double* PK = which < 0 ? pq.PK : LDC_TRIAL_ARG(const double*, PstK[which < 0 ? 0 : which]);
-    post_phase(pq, P, PK, bx, nblk, lds, tid);
+    post_phase(pq, P, PK, bx, nblk, lds, tid, local ? 0 : 1);
   };
   // A phase's argument block is fetched BEFORE the barrier that precedes the phase: the scalar loads are in flight
   // while the work-group waits for its peers instead of in front of the first fragment loads.
@@ -1925,42 +1982,42 @@ __global__ __launch_bounds__(kStageThreads, 2) void trial_kernel(const TrialArgs
     tile_stage<true, false, D1>(c, a_next, lds, bx, step0, dt, stq);
     LDC_TSTAMP(1);
     a_next = LDC_TRIAL_ARG(StageArgs, st[1]);
-    if (!grid_sync(sync, phase, nblk, tid, &S)) return;
+    if (!grid_sync(sync, phase, nblk, tid, &S, local)) return;
     LDC_TSTAMP(2);
     if (SP) {
       transforms(0);
-      if (!grid_sync(sync, phase, nblk, tid, &S)) return;
+      if (!grid_sync(sync, phase, nblk, tid, &S, local)) return;
     }
     tile_stage<SP, false, D2>(c, a_next, lds, bx, step0, dt, stq ? stq + (size_t)nblk * 64 : nullptr);
     if (DIAGV && tid == 0) { S.pdone = step0; S.drows = nblk; }     // Z and P partials of state `step0` are complete
     LDC_TSTAMP(3);
     a_next = LDC_TRIAL_ARG(StageArgs, st[2]);
-    if (!grid_sync(sync, phase, nblk, tid, &S)) return;
+    if (!grid_sync(sync, phase, nblk, tid, &S, local)) return;
     LDC_TSTAMP(4);
     if (SP) {
       transforms(1);
-      if (!grid_sync(sync, phase, nblk, tid, &S)) return;
+      if (!grid_sync(sync, phase, nblk, tid, &S, local)) return;
     }
     tile_stage<SP, false, 0>(c, a_next, lds, bx, step0, dt, stq ? stq + (size_t)nblk * 128 : nullptr);
     LDC_TSTAMP(5);
     a_next = LDC_TRIAL_ARG(StageArgs, st[3]);
-    if (!grid_sync(sync, phase, nblk, tid, &S)) return;
+    if (!grid_sync(sync, phase, nblk, tid, &S, local)) return;
     LDC_TSTAMP(6);
     if (SP) {
       transforms(2);
-      if (!grid_sync(sync, phase, nblk, tid, &S)) return;
+      if (!grid_sync(sync, phase, nblk, tid, &S, local)) return;
     }
     tile_stage<SP, true, 0>(c, a_next, lds, bx, step0, dt, stq ? stq + (size_t)nblk * 192 : nullptr);
     if (tid == 0) S.step = step0 + 1;            // one more state update done
     LDC_TSTAMP(7);
-    if (!grid_sync(sync, phase, nblk, tid, &S)) return;
+    if (!grid_sync(sync, phase, nblk, tid, &S, local)) return;
     LDC_TSTAMP(8);
     fin_work<true>(LDC_TRIAL_ARG(FinalArgs, post.fin), lds, tid, &S, bx == 0);
     LDC_TSTAMP(9);
     transforms(-1);
     LDC_TSTAMP(10);
     a_next = LDC_TRIAL_ARG(StageArgs, st[0]);
-    if (it + 1 < n_iters && !grid_sync(sync, phase, nblk, tid, &S)) return;
+    if (it + 1 < n_iters && !grid_sync(sync, phase, nblk, tid, &S, local)) return;
   }
   tile_flush(c, LDC_TRIAL_ARG(StageArgs, st[3]), lds);
   if (bx == 0 && tid == 0) {
@@ -2242,6 +2299,7 @@ struct ldc_solver {
   hipStream_t capture_stream;
   int persist_mode;          // -1 auto, 0 launch per stage, 1 persistent trial kernel
   int n_cus;                 // compute units of the handle's device
+  int n_xcds;                // its XCDs (gfx950: 32 active CUs each; a CPX partition is one)
 };
 
 
@@ -2502,10 +2560,19 @@ int enable_trial_lds() {
 bool persistent_available(const ldc_solver* s) {
   return s->p.sync != nullptr && s->nt <= s->n_cus && s->ablate == 0;
 }
-bool use_persistent(const ldc_solver* s) {
-  if (s->persist_mode == 0 || !persistent_available(s)) return false;
-  return s->persist_mode == 1 || s->nt <= LDC_PERSIST_AUTO_TILES;
+// one-XCD placement: every tile's work-group on the same XCD (one per CU)
+bool local_available(const ldc_solver* s) {
+  return persistent_available(s) && s->nt <= LDC_PERSIST_XCD_TILES && s->nt + 4 <= s->n_cus / s->n_xcds;
 }
+// 0: launch per stage   1: persistent trial kernel   2: persistent, one-XCD placement
+int persistent_mode(const ldc_solver* s) {
+  if (s->persist_mode == 0 || !persistent_available(s)) return 0;
+  if (s->persist_mode == 2) return local_available(s) ? 2 : 0;
+  if (s->persist_mode == 1) return 1;
+  if (local_available(s) && s->nt <= LDC_PERSIST_AUTO_XCD_TILES) return 2;
+  return s->nt <= LDC_PERSIST_AUTO_TILES ? 1 : 0;
+}
+bool use_persistent(const ldc_solver* s) { return persistent_mode(s) != 0; }
 
 TrialArgs make_trial_args(const ldc_solver* s, int n_iters, int with_diag) {
   TrialArgs ta;
@@ -2522,6 +2589,8 @@ TrialArgs make_trial_args(const ldc_solver* s, int n_iters, int with_diag) {
   const double* pstk[3] = {s->p.PAK, s->p.PBK, s->p.PAK};
   for (int k = 0; k < 3; ++k) { ta.Pst[k] = pst[k]; ta.PstK[k] = pstk[k]; }
   ta.n_iters = n_iters;
+  ta.local = persistent_mode(s) == 2 ? 1 : 0;
+  ta.nt = s->nt;
   ta.sync = s->p.sync;
   ta.stamps = s->stamps;
   return ta;
@@ -2531,7 +2600,9 @@ int launch_trial(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
   const TrialArgs ta = make_trial_args(s, n_iters, with_diag);
   // the barrier counts arrivals from zero in every launch (the give-up word is sticky: ldc_solver_status)
   HIP_TRY(hipMemsetAsync(s->p.sync, 0, sizeof(uint32_t) * LDC_SYNC_GIVEUP, st));
-  const dim3 grid(s->nt), block(kStageThreads);
+  // one-XCD placement: work-groups are dealt round-robin over the XCDs, so 8 per tile (and some to spare) put at
+  // least T*T of them on whichever XCD is elected; the others leave at once
+  const dim3 grid(ta.local ? s->n_xcds * (s->nt + 8) : s->nt), block(kStageThreads);
   if (s->p.stage_pressure) hipLaunchKernelGGL((trial_kernel<true, false>), grid, block, kTrialLdsBytes, st, ta);
   else if (with_diag) hipLaunchKernelGGL((trial_kernel<false, true>), grid, block, kTrialLdsBytes, st, ta);
   else hipLaunchKernelGGL((trial_kernel<false, false>), grid, block, kTrialLdsBytes, st, ta);
@@ -2682,6 +2753,7 @@ int ldc_solver_create(const ldc_problem* d, ldc_solver** out) {
   s->p = *d;
   s->device = dev;
   s->n_cus = n_cus;
+  s->n_xcds = n_cus >= 64 ? n_cus / 32 : 1;
   s->persist_mode = -1;
   s->nt = d->T * d->T;
   s->n_edge_blocks = d->tail ? (2 * d->M - 1 + kWaves - 1) / kWaves : 0;
@@ -2713,9 +2785,10 @@ int ldc_solver_set_graph_iters(ldc_solver* s, int n) {
 
 int ldc_solver_set_persistent(ldc_solver* s, int mode) {
   if (!s) return LDC_E_STATE;
-  if (mode < -1 || mode > 1) return LDC_E_ARG;
-  if (mode == 1 && (s->p.sync == nullptr || s->nt > s->n_cus)) return LDC_E_ARG;
+  if (mode < -1 || mode > 2) return LDC_E_ARG;
+  if (mode >= 1 && (s->p.sync == nullptr || s->nt > s->n_cus)) return LDC_E_ARG;
   s->persist_mode = mode;
+  if (mode == 2 && !local_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }
   return 0;
 }
 

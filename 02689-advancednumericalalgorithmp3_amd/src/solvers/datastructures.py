@@ -67,9 +67,10 @@ class SpectralParameters(Parameters):
     graph_iters: int = 32          # iterations captured per hipGraph
     nan_guard: bool = False        # quirk Q6: the reference SG spins on NaN; True = exit early
     diagnostics: bool = True       # E/Z/P every iteration, as base.py:274-276 does
-    persistent: int = -1           # iteration loop: 1 = ONE persistent launch per chunk (work-groups keep their
-                                   # tile, counter barrier per stage), 0 = one launch per RK stage (hipGraph),
-                                   # -1 = persistent where it pays (T*T <= 64 tiles, i.e. N <= 128); same results
+    persistent: int = -1           # iteration loop: 0 = one launch per RK stage (hipGraph), 1 = ONE persistent launch
+                                   # per chunk (work-groups keep their tile, counter barrier per stage), 2 = the same
+                                   # with all work-groups of the trial on one XCD (T*T <= 25 tiles, N <= 80),
+                                   # -1 = the library's choice (include/ldc_hip.h); same results in every mode
 
     def to_mlflow(self) -> dict:
         skip = {"device", "check_every", "graph_iters", "nan_guard", "diagnostics", "persistent"}

@@ -14,9 +14,11 @@ _PKG = Path(__file__).resolve().parents[3]          # .../02689-advancednumerica
 LIB_PATH = Path(os.environ.get("LDC_HIP_LIB", _PKG / "lib" / "libldc_hip.so"))
 
 REC_LEN, CTRL_LEN, SCAL_LEN, NPART = 8, 8, 8, 12
-SYNC_LEN, SYNC_GIVEUP = 64, 32
-ABI_VERSION = 3
+SYNC_LEN, SYNC_GIVEUP = 128, 96
+ABI_VERSION = 4
 PERSIST_AUTO_TILES = 0      # LDC_PERSIST_AUTO_TILES of include/ldc_hip.h (auto mode picks the persistent kernel up to here)
+PERSIST_XCD_TILES = 25      # LDC_PERSIST_XCD_TILES: mode 2 (all work-groups of a trial on one XCD) is available up to here
+PERSIST_AUTO_XCD_TILES = 0  # LDC_PERSIST_AUTO_XCD_TILES: auto mode picks mode 2 up to here
 REC_REL, REC_RU, REC_RV, REC_RP, REC_E, REC_Z, REC_P, REC_DT = range(8)
 CTRL_DONE, CTRL_ITER = 0, 1
 SCAL_DT, SCAL_UMAX, SCAL_VMAX = 0, 1, 2

@@ -287,7 +287,10 @@ class SGSolver(LidDrivenCavitySolver):
         with torch.cuda.device(self.device):      # the handle belongs to the device that is current here
             L.check(L.lib().ldc_solver_create(C.byref(pr), C.byref(h)), "ldc_solver_create")
         L.check(L.lib().ldc_solver_set_graph_iters(h, int(self.params.graph_iters)), "ldc_solver_set_graph_iters")
-        L.check(L.lib().ldc_solver_set_persistent(h, int(self.params.persistent)), "ldc_solver_set_persistent")
+        mode = int(self.params.persistent)
+        if mode == 2 and self.T * self.T > L.PERSIST_XCD_TILES:
+            mode = 0          # one-XCD placement where a trial fits one XCD (the coarse levels of a hierarchy), launches elsewhere
+        L.check(L.lib().ldc_solver_set_persistent(h, mode), "ldc_solver_set_persistent")
         self._handle, self._handle_tol = h, tol
 
     def close(self):

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define LDC_ABI_VERSION 3
+#define LDC_ABI_VERSION 4
 
 #define LDC_E_ARG      (-1)  /* null pointer / inconsistent geometry */
 #define LDC_E_STATE    (-2)  /* handle not valid for the call */
@@ -90,8 +90,10 @@ enum {
 /* sync[] (uint32) slots of the persistent trial kernel; each on a 128-byte line of its own */
 enum {
   LDC_SYNC_ARRIVE = 0,   /* arrival counter of the barrier among the trial's work-groups          */
-  LDC_SYNC_GIVEUP = 32,  /* set to 1 by a work-group whose bounded wait on the counter ran out    */
-  LDC_SYNC_LEN    = 64
+  LDC_SYNC_XCC    = 32,  /* one-XCD placement: 1 + HW XCC id the first arriving work-group elected */
+  LDC_SYNC_HEAD   = 64,  /* one-XCD placement: next tile to be claimed by a work-group of that XCD */
+  LDC_SYNC_GIVEUP = 96,  /* set to 1 by a work-group whose bounded wait on the counter ran out    */
+  LDC_SYNC_LEN    = 128
 };
 
 typedef struct ldc_problem {
@@ -187,12 +189,19 @@ int ldc_solver_enqueue(ldc_solver *s, int n_iters, int with_diagnostics, void *s
 int ldc_solver_set_graph_iters(ldc_solver *s, int iters_per_graph);
 /* How ldc_solver_enqueue runs the loop.  mode 0: one launch per RK stage (hipGraph replay); 1: the persistent   */
 /* trial kernel -- ALL n_iters iterations in ONE launch of T*T work-groups that keep their tile and meet at a    */
-/* counter barrier per stage (needs desc->sync and T*T <= CUs of the device, else LDC_E_ARG); -1 (default):      */
-/* persistent when it is available and T*T <= LDC_PERSIST_AUTO_TILES.  Same arithmetic either way: records and   */
-/* fields are bit-identical.  The persistent kernel reads the boundary values of index M-1 (tail layout) once,   */
-/* from U / UT / V / VT: they must equal those of the stage buffers UA.. / UB.. (they do after the first          */
-/* iteration that follows an upload; a call with n_iters == 1 always runs launch by launch).                      */
+/* counter barrier per stage (needs desc->sync and T*T <= CUs of the device, else LDC_E_ARG); 2: the same kernel  */
+/* with all T*T work-groups on ONE XCD (T*T <= LDC_PERSIST_XCD_TILES): the launch is 8x over-subscribed, the      */
+/* first work-group to arrive elects its XCD (HW_REG_XCC_ID), work-groups of that XCD claim the tiles, the rest   */
+/* leave at once; state then crosses work-groups through that XCD's L2 (plain stores, L1-bypassing loads, L2      */
+/* atomics) instead of write-through stores and the fabric; -1 (default): mode 2 when it is available and         */
+/* T*T <= LDC_PERSIST_AUTO_XCD_TILES, else mode 1 when T*T <= LDC_PERSIST_AUTO_TILES, else mode 0.  Same          */
+/* arithmetic in every mode: records and fields are bit-identical.  The persistent kernel reads the boundary      */
+/* values of index M-1 (tail layout) once, from U / UT / V / VT: they must equal those of the stage buffers       */
+/* UA.. / UB.. (they do after the first iteration that follows an upload; a call with n_iters == 1 always runs    */
+/* launch by launch).                                                                                             */
 #define LDC_PERSIST_AUTO_TILES 0
+#define LDC_PERSIST_XCD_TILES 25        /* one work-group per CU, 32 CUs per XCD, room left for the over-subscription to drain */
+#define LDC_PERSIST_AUTO_XCD_TILES 0
 int ldc_solver_set_persistent(ldc_solver *s, int mode);
 /* 0, or LDC_E_SYNC when a persistent launch of this handle gave up a barrier wait (a work-group was not         */
 /* resident): the state is then undefined.  Reads desc->sync on the host: SYNCHRONISES the device.               */

@@ -25,13 +25,15 @@ def test_header_and_exports_agree(lib):
     L = lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ldc_version() == lib.ABI_VERSION == 3
+    assert L.ldc_version() == lib.ABI_VERSION == 4
 
 
 def test_python_constants_match_the_header(lib):
     hdr = (ROOT / "include" / "ldc_hip.h").read_text()
     val = lambda name: int(re.search(rf"{name}\s*=?\s*(-?\d+)", hdr).group(1))        # noqa: E731
     assert val("#define LDC_PERSIST_AUTO_TILES") == lib.PERSIST_AUTO_TILES
+    assert val("#define LDC_PERSIST_XCD_TILES") == lib.PERSIST_XCD_TILES
+    assert val("#define LDC_PERSIST_AUTO_XCD_TILES") == lib.PERSIST_AUTO_XCD_TILES
     assert val("LDC_SYNC_GIVEUP") == lib.SYNC_GIVEUP and val("LDC_SYNC_LEN") == lib.SYNC_LEN
     assert val("#define LDC_NPART") == lib.NPART and val("#define LDC_ABI_VERSION") == lib.ABI_VERSION
 

@@ -35,6 +35,28 @@ def test_persistent_is_bit_identical_to_launch_per_stage(N, K, diagnostics):
         assert np.array_equal(x, y), (name, float(np.max(np.abs(x - y))))
 
 
+@pytest.mark.parametrize("N,K", [(16, 300), (24, 300), (32, 700), (40, 300), (48, 300), (64, 700), (72, 300), (80, 300)])
+@pytest.mark.parametrize("diagnostics", [True, False])
+def test_one_xcd_placement_is_bit_identical_to_launch_per_stage(N, K, diagnostics):
+    """persistent=2: the trial's work-groups claim their tiles on ONE XCD and exchange state through its L2 (plain
+    stores, L1-bypassing loads).  Same arithmetic, so again bit equality -- a stale line would break it."""
+    a = _run(N, 400.0, K, 2, diagnostics)
+    b = _run(N, 400.0, K, 0, diagnostics)
+    assert a[0].shape == (K, 8) and np.all(np.isfinite(a[0]))
+    for x, y, name in zip(a, b, ("records", "u", "v", "p")):
+        assert np.array_equal(x, y), (name, float(np.max(np.abs(x - y))))
+
+
+def test_one_xcd_placement_trajectory_vs_reference(golden_dir):
+    g = np.load(golden_dir / "g4_traj_N64_Re400_K1000.npz")
+    s = make(64, 400, persistent=2)
+    rec = s.run_iterations(1000)
+    for name in ("u", "v", "p"):
+        assert np.max(np.abs(getattr(s.arrays, name) - g[name])) < 1e-12, name
+    assert rel(rec[:, 7], g["dt"]) < 1e-12 and rel(rec[:, 1:4], g["res"]) < 1e-10
+    s.close()
+
+
 def test_persistent_chunking_does_not_matter():
     """700 iterations in chunks of 256 and in chunks of 37: same state and same records, bit for bit -- except
     Z and P of the LAST record of a chunk, which the closing stand-alone omega / palinstrophy kernels compute
@@ -80,7 +102,7 @@ def test_persistent_smoother_mode_matches_launch_path(N, levels):
     """FSG: every level in smoother mode (a transform phase after each stage) -- persistent == launches, bit for bit."""
     from solvers.spectral.fsg import FSGSolver
     out = []
-    for persistent in (1, 0):
+    for persistent in (1, 0, 2):        # 2: one-XCD placement on the levels that fit an XCD, launches on the others
         s = FSGSolver(name="spectral_fsg", Re=400.0, nx=N, ny=N, basis_type="chebyshev", CFL=1.5, beta_squared=5.0,
                       corner_treatment="smoothing", corner_smoothing=0.15, multigrid="fsg", n_levels=levels,
                       coarse_tolerance_factor=10.0, tolerance=1e-6, max_iterations=400, check_every=128,
@@ -89,9 +111,9 @@ def test_persistent_smoother_mode_matches_launch_path(N, levels):
         out.append((s.metrics.iterations, s.fields.u.copy(), s.fields.v.copy(), s.fields.p.copy(),
                     s.metrics.final_energy, s.metrics.final_enstrophy))
         s.close()
-    assert out[0][0] == out[1][0]
-    for x, y in zip(out[0][1:], out[1][1:]):
-        assert np.array_equal(x, y)
+    assert out[0][0] == out[1][0] == out[2][0]
+    for x, y, z in zip(out[0][1:], out[1][1:], out[2][1:]):
+        assert np.array_equal(x, y) and np.array_equal(z, y)
 
 
 def test_persistent_mode_switch_and_limits():
@@ -100,8 +122,14 @@ def test_persistent_mode_switch_and_limits():
     s._begin(0.0)
     assert L.lib().ldc_solver_status(s._handle) == 0
     assert L.lib().ldc_solver_set_persistent(s._handle, 7) == -1          # LDC_E_ARG
+    assert L.lib().ldc_solver_set_persistent(s._handle, 2) == 0           # 4 tiles: fits one XCD
     assert L.lib().ldc_solver_set_persistent(s._handle, 0) == 0
     s.close()
+    mid = make(96, 100.0)                       # 36 tiles: persistent yes, on one XCD (32 CUs) no
+    mid._begin(0.0)
+    assert L.lib().ldc_solver_set_persistent(mid._handle, 1) == 0
+    assert L.lib().ldc_solver_set_persistent(mid._handle, 2) == -1
+    mid.close()
     big = make(272, 100.0)                      # 17 x 17 = 289 work-groups: more than the chip has CUs
     big._begin(0.0)
     assert L.lib().ldc_solver_set_persistent(big._handle, 1) == -1

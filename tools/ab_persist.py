@@ -1,4 +1,4 @@
-"""Persistent trial kernel vs launch-per-stage path: microseconds per iteration by N (development aid).
+"""Persistent trial kernel (mode 2: all work-groups on one XCD; mode 1: anywhere) vs launch-per-stage path: microseconds per iteration by N (development aid).
     python tools/ab_persist.py [N ...]        env: AB_DIAG=0/1 (default 1), AB_ITERS"""
 import os
 import sys
@@ -12,7 +12,7 @@ diag = bool(int(os.environ.get("AB_DIAG", "1")))
 iters = int(os.environ.get("AB_ITERS", "2048"))
 for N in sizes:
     row = []
-    for mode in (1, 0):
+    for mode in (2, 1, 0):
         try:
             s = SGSolver(name="spectral", Re=1000.0, nx=N, ny=N, basis_type="chebyshev", CFL=1.5, tolerance=0.0,
                          max_iterations=10**9, check_every=4096, graph_iters=32, persistent=mode)
@@ -30,5 +30,5 @@ for N in sizes:
         except Exception as exc:          # e.g. persistent not available at this size
             row.append(float("nan"))
             print(f"N={N} mode={mode}: {exc}", flush=True)
-    print(f"N={N:4d} diag={int(diag)}  persistent {row[0]:8.2f} us/iter   launches {row[1]:8.2f} us/iter   "
-          f"ratio {row[1] / row[0]:.2f}x", flush=True)
+    print(f"N={N:4d} diag={int(diag)}  one-XCD {row[0]:8.2f}   persistent {row[1]:8.2f}   launches {row[2]:8.2f} us/iter   "
+          f"launches / one-XCD {row[2] / row[0]:.2f}x   launches / persistent {row[2] / row[1]:.2f}x", flush=True)

@@ -1,5 +1,5 @@
 """Phase timing inside the persistent trial kernel (development aid): cycle stamps of the last iteration of a launch.
-    python tools/pstamps.py N [diag]"""
+    python tools/pstamps.py N [diag] [mode: 1 anywhere, 2 one XCD]"""
 import os
 import sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "02689-advancednumericalalgorithmp3_amd", "src"))
@@ -10,8 +10,9 @@ from solvers.spectral.sg import SGSolver
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 diag = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+mode = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 s = SGSolver(name="spectral", Re=1000.0, nx=N, ny=N, basis_type="chebyshev", CFL=1.5, tolerance=0.0,
-             max_iterations=10**9, check_every=4096, graph_iters=32, persistent=1)
+             max_iterations=10**9, check_every=4096, graph_iters=32, persistent=mode)
 s.run_iterations(300, diagnostics=bool(diag))
 nt = s.T * s.T
 buf = torch.zeros(5 * nt * 64, dtype=torch.float64, device="cuda")
@@ -26,7 +27,7 @@ for rep in range(5):
     inner.append(np.diff(allst[1:].reshape(4, nt, 8, 8)[..., :7], axis=-1))     # [stage, wg, wave, point]
 d = np.median(np.stack(acc), axis=0)          # cycles, per work-group
 di = np.median(np.stack(inner), axis=0)
-print(f"N={N} T={s.T} diag={diag}: cycles per phase (median over 5 launches); mean / max over work-groups; us at 2.4 GHz")
+print(f"N={N} T={s.T} diag={diag} mode={mode}: cycles per phase (median over 5 launches); mean / max over work-groups; us at 2.4 GHz")
 for k, n in enumerate(names):
     print(f"  {n:8s} mean {d[:, k].mean():9.0f}  max {d[:, k].max():9.0f}   {d[:, k].mean() / 2400:7.2f} us")
 print(f"  total    {d.sum(axis=1).mean():9.0f}   {d.sum(axis=1).mean() / 2400:7.2f} us (without the closing barrier)")
