@@ -531,6 +531,10 @@ __device__ __forceinline__ void mfma_role(const RoleFrags& f, const ExtraFrags& 
     acc[3] = MFMA_F64(f.a1[s], f.b1[s], acc[3]);
   }
   if (GP) {
+    // The fifth contraction goes LAST, and the scheduler must leave it there: its operands were requested at the top
+    // of this group, and hipcc otherwise interleaves these MFMAs with the sixteen above (one after every four: the
+    // accumulators are independent), so that the wave waits for the extra fragments ~300 cycles after asking for them.
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const double p = (x4 == 1) ? f.a0[s] : x.a2[s];
