@@ -281,8 +281,12 @@ def main():
     rank, world, local = dist.rank, dist.world, dist.local_rank
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    # (LDC_DIST_BACKEND=gloo + fewer cards than ranks: a rehearsal of the multi-rank flow on a one-GPU box; the ranks
+    #  then share the card and the rates mean nothing)
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
-    dist.init("nccl")          # RCCL; used for the barrier and the max-over-ranks of the elapsed time only
+    dist.local_rank = local
+    dist.init(os.environ.get("LDC_DIST_BACKEND", "nccl"))   # RCCL; used for the barrier and the max-over-ranks of the elapsed time only
     barrier = dist.barrier
 
     import __graft_entry__ as g
