@@ -2763,7 +2763,7 @@ int ldc_solver_create(const ldc_problem* d, ldc_solver** out) {
   s->n_edge_blocks = d->tail ? (2 * d->M - 1 + kWaves - 1) / kWaves : 0;
   s->n_pedge_blocks = d->tail ? (d->M + kWaves - 1) / kWaves : 0;
   if (d->partials_stride < (int64_t)(s->nt + s->n_edge_blocks) * LDC_NPART) { delete s; return LDC_E_ARG; }
-  s->iters_per_graph = 32;
+  s->iters_per_graph = 64;
   s->ablate = 0;
   s->stamps = nullptr;
   s->graph[0] = s->graph[1] = nullptr;

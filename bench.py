@@ -26,7 +26,7 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE J
               until at least 0.25 s have been timed (K = 20 lasts one millisecond: a single such region measures
               the host's launch latency, not the device); `ms_per_step` is the MEDIAN region / K, `reps` says how
               many regions there were, `launch_path` what the K iterations were enqueued as ("graph": hipGraph
-              replays of min(32, K)-iteration captures that divide K, "graph+eager" when K has a remainder,
+              replays of captures of at most 64 iterations that divide K, "graph+eager" when K has a remainder,
               "persistent": one launch of the persistent trial kernel).
 * farm      : a second, sweep-shaped measurement for the multi-GPU runs -- every rank advances a BATCH of
               `trials_per_gpu` equal-N trials with shared launches (what main.py does with the trials a rank owns
@@ -62,13 +62,14 @@ def flops_per_step(N: int, diagnostics: bool) -> float:
 
 def graph_iters_for(K: int) -> int:
     """Iterations per hipGraph capture so that K iterations are whole replays where possible: the largest
-    divisor of K that is <= 32 (K itself when K <= 32); below 8 the captures get too short to amortise a
-    replay, then 32 with an eager remainder."""
-    best = max(d for d in range(1, min(K, 32) + 1) if K % d == 0)
-    return best if best >= 8 or best == K else 32
+    divisor of K that is <= 64 (K itself when K <= 64); below 8 the captures get too short to amortise a
+    replay, then 64 with an eager remainder.  (32 -> 64 iterations per graph: 50.84 -> 50.65 us per iteration at
+    N=256, flat beyond: tools/ab_graph_iters.py)"""
+    best = max(d for d in range(1, min(K, 64) + 1) if K % d == 0)
+    return best if best >= 8 or best == K else 64
 
 
-def make_solver(N, Re, device, graph_iters=32, persistent=-1):
+def make_solver(N, Re, device, graph_iters=64, persistent=-1):
     from solvers.spectral.sg import SGSolver
     return SGSolver(name="spectral", Re=Re, lid_velocity=1.0, Lx=1.0, Ly=1.0, nx=N, ny=N,
                     tolerance=0.0, max_iterations=10**9, basis_type="chebyshev", CFL=1.5,

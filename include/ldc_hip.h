@@ -185,7 +185,7 @@ int ldc_prime(ldc_solver *s, void *stream);
 /* n_iters iterations of base.py:243-313 enqueued on `stream` (hipGraph replay where     */
 /* possible); with_diagnostics=0 gives the step()-only loop.  Does not synchronise.      */
 int ldc_solver_enqueue(ldc_solver *s, int n_iters, int with_diagnostics, void *stream);
-/* iterations captured per graph (default 32); must be set before the first enqueue      */
+/* iterations captured per graph (default 64); must be set before the first enqueue      */
 int ldc_solver_set_graph_iters(ldc_solver *s, int iters_per_graph);
 /* How ldc_solver_enqueue runs the loop.  mode 0: one launch per RK stage (hipGraph replay); 1: the persistent   */
 /* trial kernel -- ALL n_iters iterations in ONE launch of T*T work-groups that keep their tile and meet at a    */
