@@ -902,8 +902,11 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
     }
     if (DIAG == 1) {
       const double w = valid ? (vx - uy) : 0.0;          // sg.py:510-522 on phi^(n+1) (= this stage's input)
-      st_out(a.W + ij, w, a.wt);
-      if (owner) tw[ti * 17 + tj] = w; else st_out(a.WT + (size_t)j * LD + i, w, a.wt);
+      // a tile node's omega goes to the packed twins only (below): nobody reads the row-major body of W / WT before
+      // the stand-alone omega pass that closes an enqueue rewrites it; the nodes of index M-1 are read row-major
+      // by stage 2 (rank-1 completion and job rows)
+      if (owner) tw[ti * 17 + tj] = w;
+      else { st_out(a.W + ij, w, a.wt); st_out(a.WT + (size_t)j * LD + i, w, a.wt); }
       dsum = valid ? wq * w * w : 0.0;
     }
     if (DIAG == 2) {
@@ -971,7 +974,6 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
       st_out(a.UoutT + ot, tu[tc * 17 + tr], a.wt);
       st_out(a.VoutT + ot, tv[tc * 17 + tr], a.wt);
     }
-    if (DIAG == 1) st_out(a.WT + ot, tw[tc * 17 + tr], a.wt);
     // packed twins of this tile: block (I, J) of the array, block (J, I) of its transposed copy, 16 bytes per
     // store: thread h = tid & 127 stores doubles 2h, 2h+1 of a 2-KB block = elements (row pr, columns pc, pc+1);
     // threads 0..127 take the u (and omega) arrays, threads 128..255 the v (and p) arrays
