@@ -20,7 +20,9 @@
 //   launch per RK stage  stage_kernel x 4 + post_kernel (finalize block first, pressure transforms), hipGraph replays;
 //                        the product path at every size
 //   persistent           trial_kernel: all iterations of a chunk in ONE launch, work-groups keep their tile's state in
-//                        registers, a counter barrier per stage; bit-identical, opt-in, measured slower
+//                        registers, a counter barrier per stage; bit-identical, opt-in, measured slower;
+//                        with T*T <= 25 optionally all on ONE XCD, elected at run time (state then crosses through
+//                        that XCD's L2: plain stores, L1-bypassing loads)
 //
 // MFMA lane maps (v_mfma_f64_16x16x4_f64; pinned by tests/test_gpu_parity.py::test_mfma_lane_maps):
 //   A: lane l holds A[row l&15][k l>>4]      B: lane l holds B[k l>>4][col l&15]
