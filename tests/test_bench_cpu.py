@@ -1,0 +1,48 @@
+"""bench.py's host-side helpers (no GPU): the hipGraph length it captures for a given --steps, the flop count of
+SURVEY 8d it prices the roofline with, and the fields of the committed bench line of the round."""
+import importlib.util
+import json
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", ROOT / "bench.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_graph_length_divides_the_timed_steps():
+    b = _bench()
+    for K in (1, 5, 20, 32, 50, 64, 100, 512, 2000, 4000):
+        g = b.graph_iters_for(K)
+        assert 1 <= g <= 64
+        if K <= 64:
+            assert g == K                       # one capture holds the whole region
+        else:
+            assert K % g == 0 or g == 64        # whole replays, or 64 with an eager remainder
+    assert b.graph_iters_for(4000) == 50 and b.graph_iters_for(20) == 20 and b.graph_iters_for(67) == 64
+
+
+def test_flop_count_is_the_necessary_one():
+    b = _bench()
+    M, Mi = 257, 255
+    assert b.flops_per_step(256, False) == 68.0 * M**3 + 2.0 * M * Mi * (M + Mi)
+    assert b.flops_per_step(256, True) - b.flops_per_step(256, False) == 8.0 * M**3
+
+
+def test_committed_bench_line_keeps_the_contract():
+    files = sorted((ROOT / "profiles").glob("r*_bench.json"))
+    assert files, "no committed bench line"
+    d = json.loads(files[-1].read_text())
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["dtype"] == "f64" and d["unit"] == "steps/s" and d["vs_baseline"] is None and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and "sample" in c
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-6
