@@ -2617,10 +2617,27 @@ int launch_trial(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+// Captures record kernel launches on a private non-blocking stream and nothing else, so no call anywhere needs to be
+// prohibited while one runs: relaxed mode.  (In the stricter modes HIP refuses, for instance, a synchronous copy in
+// ANOTHER host thread while this one captures -- sweeps advance two batches from two threads, solve_concurrently.)
+constexpr hipStreamCaptureMode kCaptureMode = hipStreamCaptureModeRelaxed;
+
+// A small synchronous copy that stays off the legacy stream (which would wait for, and order itself against, every
+// blocking stream of the process): a private non-blocking stream, waited for.
+hipError_t copy_now(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  hipStream_t st = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  if (e != hipSuccess) return e;
+  e = hipMemcpyAsync(dst, src, bytes, kind, st);
+  const hipError_t w = hipStreamSynchronize(st);
+  (void)hipStreamDestroy(st);
+  return e != hipSuccess ? e : w;
+}
+
 int build_graph(ldc_solver* s, int with_diag) {
   if (s->capture_stream == nullptr) HIP_TRY(hipStreamCreateWithFlags(&s->capture_stream, hipStreamNonBlocking));
   hipGraph_t g = nullptr;
-  HIP_TRY(hipStreamBeginCapture(s->capture_stream, hipStreamCaptureModeThreadLocal));
+  HIP_TRY(hipStreamBeginCapture(s->capture_stream, kCaptureMode));
   int e = 0;
   for (int it = 0; it < s->iters_per_graph && e == 0; ++it) e = launch_iteration(s, with_diag, s->capture_stream);
   hipError_t ce = hipStreamEndCapture(s->capture_stream, &g);
@@ -2679,7 +2696,7 @@ int batch_closing_diagnostics(ldc_batch* b, hipStream_t st) {
 int batch_build_graph(ldc_batch* b, int with_diag) {
   if (b->capture_stream == nullptr) HIP_TRY(hipStreamCreateWithFlags(&b->capture_stream, hipStreamNonBlocking));
   hipGraph_t g = nullptr;
-  HIP_TRY(hipStreamBeginCapture(b->capture_stream, hipStreamCaptureModeThreadLocal));
+  HIP_TRY(hipStreamBeginCapture(b->capture_stream, kCaptureMode));
   int e = 0;
   for (int it = 0; it < b->iters_per_graph && e == 0; ++it) e = batch_launch_iteration(b, with_diag, b->capture_stream);
   hipError_t ce = hipStreamEndCapture(b->capture_stream, &g);
@@ -2804,7 +2821,8 @@ int ldc_solver_status(ldc_solver* s) {
   if (!s) return LDC_E_STATE;
   if (s->p.sync == nullptr) return 0;
   uint32_t flag = 0;
-  HIP_TRY(hipMemcpy(&flag, s->p.sync + LDC_SYNC_GIVEUP, sizeof(flag), hipMemcpyDeviceToHost));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(copy_now(&flag, s->p.sync + LDC_SYNC_GIVEUP, sizeof(flag), hipMemcpyDeviceToHost));
   return flag ? LDC_E_SYNC : 0;
 }
 
@@ -2930,7 +2948,7 @@ int ldc_batch_create(ldc_solver* const* solvers, int n_trials, void* workspace, 
   auto carve = [&](size_t bytes) { char* r = w; w += up(bytes); return r; };
   hipError_t he = hipSuccess;
   auto put = [&](void* dst, const void* src, size_t bytes) {
-    if (he == hipSuccess) he = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = copy_now(dst, src, bytes, hipMemcpyHostToDevice);
   };
   for (int k = 0; k < 4; ++k) {
     std::vector<StageArgs> h(n_trials);

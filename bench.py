@@ -109,27 +109,39 @@ def timed_regions(s, K, diagnostics, dist, min_seconds=0.25, max_reps=2000):
 
 
 def farm_rate(N, B, device, dist, seconds=0.3):
-    """Sweep-shaped load: B equal-N trials per rank advanced by shared launches (solvers.spectral.batched);
-    returns trial-iterations per second of this rank's batch and the iterations timed."""
+    """Sweep-shaped load: B equal-N trials per rank, advanced the way main.py advances the trials a rank owns -- two
+    batches of B/2 with shared launches (solvers.spectral.batched) on two HIP streams, so that the launches of one
+    half fill the ramp / drain / hand-over gaps of the other (LDC_BATCH_STREAMS=1: one batch on one stream);
+    returns trial-iterations per second of this rank and the iterations timed per trial."""
     import torch
-    from solvers.spectral.batched import BatchedSGSolver
+    from solvers.spectral.batched import BatchedSGSolver, run_concurrently
     kw = dict(name="spectral", lid_velocity=1.0, Lx=1.0, Ly=1.0, nx=N, ny=N, tolerance=0.0, max_iterations=10**9,
               basis_type="chebyshev", CFL=1.5, beta_squared=5.0, corner_treatment="smoothing", multigrid="none",
-              device=device, check_every=4096, graph_iters=32)
+              device=device, check_every=4096, graph_iters=64)
     trials = [dict(kw, Re=1000.0, corner_smoothing=0.02 + 0.01 * q) for q in range(B)]
-    b = BatchedSGSolver(trials)
-    b.run_iterations(64, diagnostics=False)                      # edge fix, graph build
+    n_streams = max(1, min(int(os.environ.get("LDC_BATCH_STREAMS", "2")), B))
+    cut = [(B * k) // n_streams for k in range(n_streams + 1)]
+    halves = [BatchedSGSolver(trials[cut[k]:cut[k + 1]]) for k in range(n_streams)]
+    run_concurrently(halves, lambda b: b.run_iterations(64, diagnostics=False), device)      # edge fix, graph build
     K = 512
+    state = {"n": 0}
+
+    def advance(b):
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < seconds or n == 0:
+            b.run_iterations(K, diagnostics=False)
+            n += K
+        b.iterations_timed = n
+
     dist.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n = 0
-    while time.perf_counter() - t0 < seconds or n == 0:
-        b.run_iterations(K, diagnostics=False)
-        n += K
+    dt = run_concurrently(halves, advance, device)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    b.close()
-    return B * n / dt, n
+    done = sum(len(b) * b.iterations_timed for b in halves)
+    state["n"] = min(b.iterations_timed for b in halves)
+    for b in halves:
+        b.close()
+    return done / dt, state["n"]
 
 
 def stage_kernel_time(s, bursts=20, pairs_per_burst=100):
@@ -320,8 +332,9 @@ def main():
         rates = dist.all_gather_object(rate)
         farm = {"value": float(sum(rates)), "unit": "trial-iterations/s", "n_gpus": world, "trials_per_gpu": fB, "N": fN,
                 "per_gpu": [float(r) for r in rates], "iterations_timed_per_trial": n_it,
-                "workload": f"{fB} batched SG trials of N={fN} per GPU (shared launches, step()-only loop), "
-                            "the per-rank load of main.py's sweep farm"}
+                "streams": max(1, min(int(os.environ.get("LDC_BATCH_STREAMS", "2")), fB)),
+                "workload": f"{fB} SG trials of N={fN} per GPU as main.py advances the trials a rank owns: two batches with "
+                            "shared launches on two HIP streams (step()-only loop)"}
 
     out = None
     if rank == 0:

@@ -165,3 +165,46 @@ def test_batched_fsg_rejects_mixed_hierarchies():
     from solvers.spectral.batched import BatchedFSGSolver
     with pytest.raises(ValueError):
         BatchedFSGSolver([fsg_kw(32, 100), fsg_kw(32, 100, n_levels=1)])
+
+
+def test_two_halves_on_two_streams_equal_stand_alone_solves():
+    """main.py runs a rank's equal-N trials as two batches on two HIP streams (solve_concurrently): same kernels per
+    trial, so converged solves keep their iteration counts and fields bit for bit; the wall-time shares add up."""
+    from solvers.spectral.batched import BatchedSGSolver, solve_concurrently
+    from solvers.spectral.sg import SGSolver
+    trials = [kw(32, 100, 0.15, tolerance=1e-4), kw(32, 400, 0.10, tolerance=1e-4), kw(32, 50, 0.30, tolerance=1e-4),
+              kw(32, 250, 0.05, tolerance=1e-4, max_iterations=700), kw(32, 100, 0.15, tolerance=1e-4, beta_squared=3.0)]
+    halves = [BatchedSGSolver(trials[:3]), BatchedSGSolver(trials[3:])]
+    wall = solve_concurrently(halves)
+    solvers = halves[0].solvers + halves[1].solvers
+    assert halves[0].batch_seconds == halves[1].batch_seconds == wall and halves[0].batch_size == 5
+    assert abs(sum(s.metrics.wall_time_seconds for s in solvers) - wall) < 1e-6 * max(1.0, wall)
+    for t, s in zip(trials, solvers):
+        one = SGSolver(**t)
+        one.solve()
+        assert s.metrics.iterations == one.metrics.iterations and s.metrics.converged == one.metrics.converged
+        assert np.array_equal(s.fields.u, one.fields.u) and np.array_equal(s.fields.p, one.fields.p)
+        one.close()
+    assert solvers[3].metrics.iterations == 700 and not solvers[3].metrics.converged
+    for b in halves:
+        b.close()
+
+
+def test_fsg_batches_on_two_streams_equal_stand_alone_solves():
+    from solvers.spectral.batched import BatchedFSGSolver, solve_concurrently
+    from solvers.spectral.fsg import FSGSolver
+    base = dict(name="spectral_fsg", nx=32, ny=32, basis_type="chebyshev", CFL=1.5, beta_squared=5.0,
+                corner_treatment="smoothing", multigrid="fsg", n_levels=2, coarse_tolerance_factor=10.0, tolerance=1e-5,
+                max_iterations=4000, check_every=128, graph_iters=16)
+    trials = [dict(base, Re=100.0, corner_smoothing=0.15), dict(base, Re=400.0, corner_smoothing=0.08),
+              dict(base, Re=200.0, corner_smoothing=0.25)]
+    halves = [BatchedFSGSolver(trials[:2]), BatchedFSGSolver(trials[2:])]
+    solve_concurrently(halves)
+    for t, s in zip(trials, halves[0].solvers + halves[1].solvers):
+        one = FSGSolver(**t)
+        one.solve()
+        assert s.metrics.iterations == one.metrics.iterations
+        assert np.array_equal(s.fields.u, one.fields.u) and np.array_equal(s.fields.v, one.fields.v)
+        one.close()
+    for b in halves:
+        b.close()
