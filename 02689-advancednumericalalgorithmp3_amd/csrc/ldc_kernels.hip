@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -2622,20 +2623,42 @@ int launch_trial(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
 // ANOTHER host thread while this one captures -- sweeps advance two batches from two threads, solve_concurrently.)
 constexpr hipStreamCaptureMode kCaptureMode = hipStreamCaptureModeRelaxed;
 
+// The rare, heavy runtime operations of the library -- graph capture and instantiation, destruction of graph
+// executables, the creation-time argument copy of a batch -- run one at a time per process, on ONE private non-blocking
+// stream per device that is created on first use and never destroyed.  Sweeps drive the library from two host threads
+// (solve_concurrently); with a capture stream created and destroyed per handle, a batch being set up in one thread
+// while the other waited on its stream aborted inside the HIP runtime.  The hot calls (graph and kernel launches on
+// the caller's stream) take no lock.  This mutex and these streams are the only process-wide state of the library.
+std::mutex g_setup_mutex;
+hipStream_t g_setup_stream[64] = {};
+hipError_t setup_stream(hipStream_t* out) {      // call with g_setup_mutex held
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (g_setup_stream[dev] == nullptr) {
+    e = hipStreamCreateWithFlags(&g_setup_stream[dev], hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+  }
+  *out = g_setup_stream[dev];
+  return hipSuccess;
+}
+
 // A small synchronous copy that stays off the legacy stream (which would wait for, and order itself against, every
-// blocking stream of the process): a private non-blocking stream, waited for.
+// blocking stream of the process): the private stream, waited for.
 hipError_t copy_now(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  std::lock_guard<std::mutex> lock(g_setup_mutex);
   hipStream_t st = nullptr;
-  hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  hipError_t e = setup_stream(&st);
   if (e != hipSuccess) return e;
   e = hipMemcpyAsync(dst, src, bytes, kind, st);
   const hipError_t w = hipStreamSynchronize(st);
-  (void)hipStreamDestroy(st);
   return e != hipSuccess ? e : w;
 }
 
 int build_graph(ldc_solver* s, int with_diag) {
-  if (s->capture_stream == nullptr) HIP_TRY(hipStreamCreateWithFlags(&s->capture_stream, hipStreamNonBlocking));
+  std::lock_guard<std::mutex> lock(g_setup_mutex);
+  HIP_TRY(setup_stream(&s->capture_stream));
   hipGraph_t g = nullptr;
   HIP_TRY(hipStreamBeginCapture(s->capture_stream, kCaptureMode));
   int e = 0;
@@ -2694,7 +2717,8 @@ int batch_closing_diagnostics(ldc_batch* b, hipStream_t st) {
 }
 
 int batch_build_graph(ldc_batch* b, int with_diag) {
-  if (b->capture_stream == nullptr) HIP_TRY(hipStreamCreateWithFlags(&b->capture_stream, hipStreamNonBlocking));
+  std::lock_guard<std::mutex> lock(g_setup_mutex);
+  HIP_TRY(setup_stream(&b->capture_stream));
   hipGraph_t g = nullptr;
   HIP_TRY(hipStreamBeginCapture(b->capture_stream, kCaptureMode));
   int e = 0;
@@ -2795,8 +2819,10 @@ int ldc_solver_create(const ldc_problem* d, ldc_solver** out) {
 
 int ldc_solver_destroy(ldc_solver* s) {
   if (!s) return LDC_E_STATE;
-  for (int q = 0; q < 2; ++q) if (s->graph[q]) (void)hipGraphExecDestroy(s->graph[q]);
-  if (s->capture_stream) (void)hipStreamDestroy(s->capture_stream);
+  {
+    std::lock_guard<std::mutex> lock(g_setup_mutex);
+    for (int q = 0; q < 2; ++q) if (s->graph[q]) (void)hipGraphExecDestroy(s->graph[q]);
+  }
   delete s;
   return 0;
 }
@@ -2998,8 +3024,10 @@ int ldc_batch_create(ldc_solver* const* solvers, int n_trials, void* workspace, 
 
 int ldc_batch_destroy(ldc_batch* b) {
   if (!b) return LDC_E_STATE;
-  for (int q = 0; q < 2; ++q) if (b->graph[q]) (void)hipGraphExecDestroy(b->graph[q]);
-  if (b->capture_stream) (void)hipStreamDestroy(b->capture_stream);
+  {
+    std::lock_guard<std::mutex> lock(g_setup_mutex);
+    for (int q = 0; q < 2; ++q) if (b->graph[q]) (void)hipGraphExecDestroy(b->graph[q]);
+  }
   delete b;
   return 0;
 }

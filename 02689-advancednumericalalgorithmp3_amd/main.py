@@ -105,33 +105,103 @@ def run_solver(cfg: dict, out_dir: Path, device: str = None) -> dict:
     return rec
 
 
-def run_batch(cfgs: list, out_dirs: list, device: str = None) -> list:
-    """Several SG (or several FSG) trials of equal N on one GPU, advanced by the same launches
-    (solvers.spectral.batched)."""
-    from solvers.spectral.batched import BatchedFSGSolver, BatchedSGSolver, solve_concurrently
-    nodes = []
-    for cfg in cfgs:
-        node = {k: v for k, v in cfg["solver"].items() if k != "_target_"}
-        if device is not None:
-            node["device"] = device
-        nodes.append(node)
+def run_batches(groups: list, device: str = None) -> list:
+    """groups: [(cfgs, out_dirs)], each a set of SG (or FSG) trials of equal N that can share their launches.
+    Returns the record lists in the same order.
+
+    Every group is cut into (at most) as many batches as there are worker streams (LDC_BATCH_STREAMS, default 2;
+    solvers.spectral.batched); the batches of ALL groups then go, longest first, through a pool of that many host
+    threads, one HIP stream each.  The launches of the batch on one stream fill the ramp / drain / hand-over gaps of the
+    batch on the other -- within one N (two halves of a batch: up to 1.3x) and across sizes (the small-N groups of a
+    grid run in the shadow of the large ones).  A batch that fails leaves error records for its trials only.
+    Records (validation, artefacts, MLflow) are made afterwards, in the caller's thread."""
+    import threading
+    from solvers.spectral.batched import BatchedFSGSolver, BatchedSGSolver, run_concurrently
+    n_workers = max(1, int(os.environ.get("LDC_BATCH_STREAMS", "2")))
+    tasks = []
+    for gi, (cfgs, _) in enumerate(groups):
+        parts = max(1, min(n_workers, len(cfgs)))
+        cut = [(len(cfgs) * k) // parts for k in range(parts + 1)]
+        for k in range(parts):
+            tasks.append(((cut[k + 1] - cut[k]) * float(cfgs[0]["N"]) ** 5, gi, cut[k], cut[k + 1]))
+    tasks.sort(key=lambda t: (-t[0], t[1], t[2]))
+    n_tasks = len(tasks)
+    lock, done = threading.Lock(), {}
+
+    def worker(_):
+        while True:
+            with lock:
+                if not tasks:
+                    return
+                _, gi, lo, hi = tasks.pop(0)
+            part = groups[gi][0][lo:hi]
+            try:
+                nodes = []
+                for cfg in part:
+                    node = {k: v for k, v in cfg["solver"].items() if k != "_target_"}
+                    if device is not None:
+                        node["device"] = device
+                    nodes.append(node)
+                fsg = part[0]["solver"]["_target_"].endswith("FSGSolver")
+                if len(nodes) == 1:                 # alone on its stream: the single-trial kernels (no argument blocks in memory)
+                    batch = _OneTrial(C.instantiate(dict(nodes[0], _target_=part[0]["solver"]["_target_"])))
+                else:
+                    batch = (BatchedFSGSolver if fsg else BatchedSGSolver)(nodes)     # built on this worker's stream
+                batch.solve()
+                done[(gi, lo)] = batch
+            except Exception as exc:                # the other batches go on; the farm reports the failure
+                log.exception("batch of %d trials at N=%s failed", len(part), part[0]["N"])
+                done[(gi, lo)] = exc
+
     t0 = time.perf_counter()
-    fsg = cfgs[0]["solver"]["_target_"].endswith("FSGSolver")
-    cls = BatchedFSGSolver if fsg else BatchedSGSolver
-    # two halves on two HIP streams (LDC_BATCH_STREAMS=1: one batch on the caller's stream): launches of one half fill
-    # the ramp / drain / hand-over gaps of the other; never slower, up to 1.3x faster (solve_concurrently)
-    n_streams = max(1, min(int(os.environ.get("LDC_BATCH_STREAMS", "2")), len(nodes)))
-    cut = [(len(nodes) * k) // n_streams for k in range(n_streams + 1)]
-    batches = [cls(nodes[cut[k]:cut[k + 1]]) for k in range(n_streams)]
-    solve_concurrently(batches, device)
-    solvers = [s for b in batches for s in b.solvers]
-    recs = [make_record(cfg, s, d, t0) for cfg, s, d in zip(cfgs, solvers, out_dirs)]
-    for r in recs:      # the wall time of the lot; a trial's wall_time_seconds is its share of it
-        r["solve_batch_seconds"], r["solve_batch_size"] = batches[0].batch_seconds, batches[0].batch_size
-        r["solve_streams"] = n_streams
-    for b in batches:
-        b.close()
-    return recs
+    n_threads = max(1, min(n_workers, n_tasks))
+    wall = run_concurrently(list(range(n_threads)), worker, device)
+    good = [b for b in done.values() if not isinstance(b, Exception)]
+    busy = sum(b.batch_seconds for b in good)
+    out = []
+    for gi, (cfgs, dirs) in enumerate(groups):
+        recs = []
+        for (g2, lo), batch in sorted(((k, v) for k, v in done.items() if k[0] == gi), key=lambda kv: kv[0][1]):
+            if isinstance(batch, Exception):
+                hi = min([k[1] for k in done if k[0] == gi and k[1] > lo] + [len(cfgs)])
+                recs += [dict(error=repr(batch), objective=math.inf) for _ in range(lo, hi)]
+                continue
+            for q, s in enumerate(batch.solvers):
+                if n_threads > 1 and busy > 0:      # the shares of all trials add up to the pool's wall time
+                    s.metrics.wall_time_seconds *= wall / busy
+                r = make_record(cfgs[lo + q], s, dirs[lo + q], t0)
+                # the batch's own wall time (batches of other streams ran beside it) and the pool's
+                r["solve_batch_seconds"], r["solve_batch_size"] = batch.batch_seconds, len(batch)
+                r["solve_pool_seconds"], r["solve_streams"], r["solve_group_size"] = wall, n_threads, len(cfgs)
+                recs.append(r)
+            batch.close()
+        out.append(recs)
+    return out
+
+
+class _OneTrial:
+    """A "batch" of one: the plain solver behind the interface run_batches drives."""
+
+    def __init__(self, solver):
+        self.solvers = [solver]
+        self.batch_seconds, self.batch_size = 0.0, 1
+
+    def __len__(self):
+        return 1
+
+    def solve(self):
+        t0 = time.perf_counter()
+        self.solvers[0].solve()
+        self.batch_seconds = time.perf_counter() - t0
+
+    def close(self):
+        if hasattr(self.solvers[0], "close"):
+            self.solvers[0].close()
+
+
+def run_batch(cfgs: list, out_dirs: list, device: str = None) -> list:
+    """Several SG (or several FSG) trials of equal N on one GPU (run_batches with one group)."""
+    return run_batches([(cfgs, out_dirs)], device)[0]
 
 
 _TRACKER = None        # utilities.tracking.sweep.SweepTracker of the running sweep (None: single run / no mlflow)
@@ -263,23 +333,29 @@ def main(argv=None) -> float | None:
             sv = c["solver"]
             share.setdefault((sv["_target_"], int(c["N"]), int(sv.get("n_levels", 0)), bool(sv.get("diagnostics", True))),
                              []).append(q)
+        groups, where = [], []
         for (target, _, _, _), members in share.items():
             if target in (SG, FSG) and len(members) > 1 and max_batch > 1:
                 for lo in range(0, len(members), max_batch):
                     part = members[lo: lo + max_batch]
                     log.info("batch of %d trials at N=%s on %s", len(part), cfgs[part[0]]["N"], device or "cuda:0")
-                    recs = run_batch([cfgs[q] for q in part], [root_dir / str(offset + items[q][0]) for q in part], device)
-                    for q, r in zip(part, recs):
-                        out[q] = r
+                    groups.append(([cfgs[q] for q in part], [root_dir / str(offset + items[q][0]) for q in part]))
+                    where.append(part)
             else:
                 for q in members:
                     out[q] = run_solver(cfgs[q], root_dir / str(offset + items[q][0]), device=device)
+        if groups:          # all batches of this rank through ONE pool of streams: sizes overlap too
+            for part, recs in zip(where, run_batches(groups, device)):
+                for q, r in zip(part, recs):
+                    out[q] = r
         for (i, _), r in zip(items, out):
             r["overrides"] = {k: v for k, v in jobs[i]}
         return out
 
     def key_of(jobs):
-        return lambda t: (t.get("N"), str(dict(jobs[t["_job"]]).get("solver", "")))
+        # ONE group per rank: run_group sorts the rank's trials into batches by itself (solver class, N, hierarchy,
+        # diagnostics) and advances all of them through one pool of streams
+        return lambda t: 0
 
     def open_parents(jobs, offset=0):
         """Job start of the reference's MLflowSweepCallback for every job of this round: rank 0 gets or creates

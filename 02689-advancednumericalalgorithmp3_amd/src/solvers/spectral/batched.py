@@ -71,7 +71,7 @@ class BatchedSGSolver:
     def close_batch(self):
         if self._batch is not None:
             import torch
-            torch.cuda.synchronize(self.solvers[0].device)
+            self.solvers[0]._sync()
             L.lib().ldc_batch_destroy(self._batch)
             self._batch = None
 
@@ -116,7 +116,7 @@ class BatchedSGSolver:
                     blocks[q].append(rows)
                     state[q] = (done, total)
             it += k
-        torch.cuda.synchronize(self.solvers[0].device)
+        self.solvers[0]._sync()
         return [(d, t, np.concatenate(b, axis=0) if b else np.zeros((0, 8))) for (d, t), b in zip(state, blocks)]
 
     def __del__(self):
@@ -134,7 +134,7 @@ class BatchedSGSolver:
         with torch.cuda.device(dev):
             L.check(L.lib().ldc_batch_enqueue(self._batch, int(n_iters), int(bool(diagnostics)), L.stream_ptr(dev)),
                     "ldc_batch_enqueue")
-            torch.cuda.synchronize(dev)
+            self.solvers[0]._sync()
         out = []
         for s, start in zip(self.solvers, starts):
             ctrl = s.d["ctrl"].cpu().numpy()

@@ -190,7 +190,7 @@ class SGSolver(LidDrivenCavitySolver):
     # ------------------------------------------------------------------ state transfer
     def _download_full(self, name: str) -> np.ndarray:
         import torch
-        torch.cuda.synchronize(self.device)
+        self._sync()
         return self.d[name][: self.M, : self.M].cpu().numpy()
 
     def _upload_full(self, name: str, a2d: np.ndarray, transposed_name: str = None):
@@ -293,10 +293,18 @@ class SGSolver(LidDrivenCavitySolver):
         L.check(L.lib().ldc_solver_set_persistent(h, mode), "ldc_solver_set_persistent")
         self._handle, self._handle_tol = h, tol
 
+    def _sync(self):
+        """Wait for this solver's work: everything it enqueues goes to the calling thread's current stream of its
+        device (``_abi``).  NOT a device-wide synchronise: with two batches advanced from two host threads
+        (batched.run_concurrently) that would also wait for the other thread's stream, and HIP refuses it outright
+        while the other thread captures a graph."""
+        import torch
+        torch.cuda.current_stream(self.device).synchronize()
+
     def close(self):
         if getattr(self, "_handle", None) is not None:
             import torch
-            torch.cuda.synchronize(self.device)
+            self._sync()
             L.lib().ldc_solver_destroy(self._handle)
             self._handle = None
 
@@ -332,7 +340,7 @@ class SGSolver(LidDrivenCavitySolver):
             rows2, done2, end2 = self._advance(n_iters - 1)
             return np.concatenate([rows1, rows2], axis=0), done2, end2
         self._abi("ldc_solver_enqueue", self._handle, n_iters, int(bool(self.params.diagnostics)))
-        torch.cuda.synchronize(self.device)
+        self._sync()
         ctrl = self.d["ctrl"].cpu().numpy()
         end, done = int(ctrl[L.CTRL_ITER]), int(ctrl[L.CTRL_DONE])
         if int(self.d["sync"][L.SYNC_GIVEUP]) != 0:
@@ -401,7 +409,7 @@ class SGSolver(LidDrivenCavitySolver):
             t.zero_()
         arr = (C.c_void_p * 11)(*[t.data_ptr() for t in outs])
         self._abi("ldc_residual_debug", self._handle, which, arr)
-        torch.cuda.synchronize(self.device)
+        self._sync()
         M = self.M
         res = {}
         for k, key in enumerate(_DEBUG_KEYS):
@@ -415,7 +423,7 @@ class SGSolver(LidDrivenCavitySolver):
         self._ensure_handle(self.params.tolerance if self._handle_tol is None else self._handle_tol)
         out = self.d["ext_val"]
         self._abi("ldc_global_quantities", self._handle, out.data_ptr())
-        torch.cuda.synchronize(self.device)
+        self._sync()
         e, z, p = out[:3].cpu().numpy()
         return {"E": float(e), "Z": float(z), "P": float(p)}
 
@@ -424,7 +432,7 @@ class SGSolver(LidDrivenCavitySolver):
         import torch
         self._ensure_handle(self.params.tolerance if self._handle_tol is None else self._handle_tol)
         self._abi("ldc_diagnostics", self._handle)
-        torch.cuda.synchronize(self.device)
+        self._sync()
         return self._download_full("W").ravel()
 
     def _eigenbasis(self):
@@ -465,7 +473,7 @@ class SGSolver(LidDrivenCavitySolver):
         full = self.d["S4"]
         full.zero_()
         full[1: M - 1, 1: M - 1] = Psi[:Mi, :Mi]
-        torch.cuda.synchronize(self.device)
+        self._sync()
         return full[:M, :M].cpu().numpy(), self.x_full, self.y_full
 
     def compute_vortex_metrics(self) -> dict:
@@ -474,7 +482,7 @@ class SGSolver(LidDrivenCavitySolver):
         self._abi("ldc_vortex_extrema",
                   self.d["S4"].data_ptr(), self.d["W"].data_ptr(), self.d["x"].data_ptr(), self.d["y"].data_ptr(),
                   self.M, self.LD, self.d["ext_val"].data_ptr(), self.d["ext_idx"].data_ptr())
-        torch.cuda.synchronize(self.device)
+        self._sync()
         val = self.d["ext_val"].cpu().numpy()
         idx = self.d["ext_idx"].cpu().numpy()
         W = self.d["W"].cpu().numpy()

@@ -11,7 +11,8 @@
  * Conventions
  *  - every pointer in `ldc_problem` is a DEVICE pointer into caller-owned memory
  *    (torch.float64 / torch.int32 tensors on the host side); the library allocates no
- *    device memory and keeps no globals.  A solver handle owns only its captured
+ *    device memory; its only process-wide state is a mutex and one private stream per device for graph captures
+ *    and creation-time copies (rare operations, serialised; the launches take no lock).  A solver handle owns only its captured
  *    hipGraph executables.  It belongs to the HIP device that is current when it is created
  *    (dynamic-LDS attributes of its kernels are set there); using it with another device
  *    current returns LDC_E_STATE.
