@@ -116,7 +116,7 @@ def run_farm(trials: list, run_trial, dist: Dist, cost=trial_cost, run_group=Non
         dt = time.perf_counter() - t0
         for (idx, _), rec in zip(grp, recs):
             rec = dict(rec)
-            # the trials of a group share every launch: the group has ONE wall time (batch_seconds);
+            # a group is handed over and comes back as a whole: it has ONE wall time (batch_seconds);
             # trial_seconds is the amortised time per trial
             rec.update(trial_index=idx, rank=dist.rank, batch_seconds=dt, batch_size=len(grp),
                        trial_seconds=dt / len(grp))
