@@ -255,6 +255,9 @@ class BatchedFSGSolver:
         return [s.metrics for s in fines]
 
 
+_WORKER_STREAMS = {}      # (device index, worker) -> torch.cuda.Stream, see run_concurrently
+
+
 def run_concurrently(batches: list, fn, device=None) -> float:
     """``fn(batch)`` for every batch object AT THE SAME TIME, one host thread and one HIP stream each; returns the
     wall time of the lot.  The streams alternate between the two stream priorities HIP offers: streams of different
@@ -268,8 +271,18 @@ def run_concurrently(batches: list, fn, device=None) -> float:
         fn(batches[0])
         return time.perf_counter() - t0
     dev = torch.device(device if device is not None else "cuda")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     here = torch.cuda.current_stream(dev)
-    streams = [torch.cuda.Stream(device=dev, priority=(-1 if k % 2 else 0)) for k in range(len(batches))]
+    # the worker streams are made once per device and kept: with a fresh pair per call the FOURTH pair of a process
+    # ran its work three to five times slower, every time (config 5 at full size, round 4 of 8: 88 s instead of 20) --
+    # which hardware queue a new stream lands on is the runtime's business, the first pair's placement is the measured one
+    streams = []
+    for k in range(len(batches)):
+        key = (dev.index, k)
+        if key not in _WORKER_STREAMS:
+            _WORKER_STREAMS[key] = torch.cuda.Stream(device=dev, priority=(-1 if k % 2 else 0))
+        streams.append(_WORKER_STREAMS[key])
     errors = [None] * len(batches)
 
     def work(k):
