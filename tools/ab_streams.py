@@ -61,6 +61,7 @@ if len(sys.argv) > 4:
     # a hardware queue, streams of one priority may (which ones do is the runtime's choice)
     prio = bool(int(os.environ.get("AB_PRIO", "0")))
     junk = [torch.cuda.Stream() for _ in range(int(os.environ.get("AB_JUNK", "0")))]    # shifts the pool position
+    junk += [torch.cuda.Stream(priority=-1) for _ in range(int(os.environ.get("AB_JUNK_HI", "0")))]
     sts = [torch.cuda.Stream(priority=(-1 if (prio and k % 2) else 0)) for k in range(S)]
     for x, st in zip(bs, sts):
         with torch.cuda.stream(st):
