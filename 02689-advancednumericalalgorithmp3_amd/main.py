@@ -199,11 +199,6 @@ class _OneTrial:
             self.solvers[0].close()
 
 
-def run_batch(cfgs: list, out_dirs: list, device: str = None) -> list:
-    """Several SG (or several FSG) trials of equal N on one GPU (run_batches with one group)."""
-    return run_batches([(cfgs, out_dirs)], device)[0]
-
-
 _TRACKER = None        # utilities.tracking.sweep.SweepTracker of the running sweep (None: single run / no mlflow)
 
 

@@ -150,3 +150,32 @@ def test_two_rank_farm_on_the_gpu(tmp_path):
             assert x["metrics"][key] == y["metrics"][key], key
     root = next(two.glob("hydra_outputs/multirun/*/*"))
     assert sorted(p.name for p in root.iterdir() if p.is_dir()) == [str(k) for k in range(8)]
+
+
+def test_a_failing_batch_costs_only_its_own_trials(tmp_path, monkeypatch):
+    """run_batches: two share groups through the pool of worker streams; one batch cannot even be built (a basis the
+    solver does not have) -- its trials come back as error records, every other batch is solved and recorded."""
+    spec = importlib.util.spec_from_file_location("ldc_main_pool", PKG / "main.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.chdir(PKG)               # data/validation is looked up relative to the package
+
+    def cfg(N, Re, **kw):
+        node = dict(_target_="solvers.spectral.sg.SGSolver", name="spectral", Re=float(Re), nx=N, ny=N, tolerance=1e-6,
+                    max_iterations=150, check_every=64, graph_iters=8)
+        node.update(kw)
+        return {"N": N, "Re": Re, "solver": node}
+
+    g32 = [cfg(32, 100), cfg(32, 400), cfg(32, 250, basis_type="fourier"), cfg(32, 50)]
+    g48 = [cfg(48, 100), cfg(48, 400)]
+    out = mod.run_batches([(g32, [tmp_path / f"a{k}" for k in range(4)]), (g48, [tmp_path / f"b{k}" for k in range(2)])])
+    assert [len(x) for x in out] == [4, 2]
+    assert ["error" in r for r in out[0]] == [False, False, True, True] and not any("error" in r for r in out[1])
+    assert all("fourier" in r["error"].lower() or "basis" in r["error"].lower() for r in out[0][2:])
+    for r in out[0][:2] + out[1]:
+        assert r["metrics"]["iterations"] == 150 and r["solve_streams"] == 2
+    from solvers.spectral.sg import SGSolver
+    one = SGSolver(**{k: v for k, v in g48[1]["solver"].items() if k != "_target_"})
+    one.solve()
+    assert out[1][1]["metrics"]["final_energy"] == one.metrics.final_energy       # the pooled trial is the stand-alone trial
+    one.close()
