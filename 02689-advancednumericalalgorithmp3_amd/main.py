@@ -118,9 +118,18 @@ def run_batches(groups: list, device: str = None) -> list:
     import threading
     from solvers.spectral.batched import BatchedFSGSolver, BatchedSGSolver, run_concurrently
     n_workers = max(1, int(os.environ.get("LDC_BATCH_STREAMS", "2")))
+    import torch
+    n_cus = torch.cuda.get_device_properties(torch.device(device) if device is not None
+                                             else torch.cuda.current_device()).multi_processor_count
     tasks = []
     for gi, (cfgs, _) in enumerate(groups):
         parts = max(1, min(n_workers, len(cfgs)))
+        # a trial whose tiles fill the chip on their own (N >= 241 on 256 CUs) gains nothing from sharing launches (two
+        # N=256 trials batched: 20.4 k trial-iterations/s, one after the other 19.7 k) but overlaps well with another
+        # stream's launches (23.4 k): such trials go through the pool one by one, on the single-trial kernels
+        n = int(cfgs[0]["N"])
+        if n_workers > 1 and ((n + 15) // 16) ** 2 >= n_cus:
+            parts = len(cfgs)
         cut = [(len(cfgs) * k) // parts for k in range(parts + 1)]
         for k in range(parts):
             tasks.append(((cut[k + 1] - cut[k]) * float(cfgs[0]["N"]) ** 5, gi, cut[k], cut[k + 1]))
