@@ -3113,4 +3113,28 @@ int ldc_mfma_peak(double* sink, int iters, int grid, void* stream) {
   return (int)hipGetLastError();
 }
 
+int ldc_stream_priority_range(int* least, int* greatest) {
+  if (!least || !greatest) return LDC_E_ARG;
+  HIP_TRY(hipDeviceGetStreamPriorityRange(least, greatest));
+  return 0;
+}
+
+int ldc_stream_create(int priority, void** stream) {
+  if (!stream) return LDC_E_ARG;
+  hipStream_t st = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_setup_mutex);
+    HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, priority));
+  }
+  *stream = st;
+  return 0;
+}
+
+int ldc_stream_destroy(void* stream) {
+  if (!stream) return LDC_E_ARG;
+  std::lock_guard<std::mutex> lock(g_setup_mutex);
+  HIP_TRY(hipStreamDestroy(as_stream(stream)));
+  return 0;
+}
+
 }  // extern "C"

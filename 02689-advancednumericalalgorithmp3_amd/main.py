@@ -109,21 +109,21 @@ def run_batches(groups: list, device: str = None) -> list:
     """groups: [(cfgs, out_dirs)], each a set of SG (or FSG) trials of equal N that can share their launches.
     Returns the record lists in the same order.
 
-    Every group is cut into (at most) as many batches as there are worker streams (LDC_BATCH_STREAMS, default 2;
-    solvers.spectral.batched); the batches of ALL groups then go, longest first, through a pool of that many host
-    threads, one HIP stream each.  The launches of the batch on one stream fill the ramp / drain / hand-over gaps of the
+    Every group is cut into two batches (solvers.spectral.batched); the batches of ALL groups then go, longest first,
+    through a pool of LDC_BATCH_STREAMS host threads (default 3: one per stream priority of the hardware), one HIP
+    stream each.  The launches of the batch on one stream fill the ramp / drain / hand-over gaps of the
     batch on the other -- within one N (two halves of a batch: up to 1.3x) and across sizes (the small-N groups of a
     grid run in the shadow of the large ones).  A batch that fails leaves error records for its trials only.
     Records (validation, artefacts, MLflow) are made afterwards, in the caller's thread."""
     import threading
     from solvers.spectral.batched import BatchedFSGSolver, BatchedSGSolver, run_concurrently
-    n_workers = max(1, int(os.environ.get("LDC_BATCH_STREAMS", "2")))
+    n_workers = max(1, int(os.environ.get("LDC_BATCH_STREAMS", "3")))
     import torch
     n_cus = torch.cuda.get_device_properties(torch.device(device) if device is not None
                                              else torch.cuda.current_device()).multi_processor_count
     tasks = []
     for gi, (cfgs, _) in enumerate(groups):
-        parts = max(1, min(n_workers, len(cfgs)))
+        parts = max(1, min(2, n_workers, len(cfgs)))      # halves: more, smaller batches measured no better (N=128)
         # a trial whose tiles fill the chip on their own (N >= 241 on 256 CUs) gains nothing from sharing launches (two
         # N=256 trials batched: 20.4 k trial-iterations/s, one after the other 19.7 k) but overlaps well with another
         # stream's launches (23.4 k): such trials go through the pool one by one, on the single-trial kernels

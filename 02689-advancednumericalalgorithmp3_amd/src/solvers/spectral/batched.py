@@ -262,7 +262,10 @@ def run_concurrently(batches: list, fn, device=None) -> float:
     """``fn(batch)`` for every batch object AT THE SAME TIME, one host thread and one HIP stream each; returns the
     wall time of the lot.  The streams alternate between the two stream priorities HIP offers: streams of different
     priority never share a hardware queue, while which streams of ONE priority do is the runtime's choice (and on a
-    shared queue nothing overlaps).  An exception in a thread is re-raised here."""
+    shared queue nothing overlaps).  HIP has three priority levels on this hardware and torch hands out two of them, so
+    the streams come from the library (``ldc_stream_create``) and are wrapped as ``torch.cuda.ExternalStream``: up to
+    three workers with a hardware queue each (normal, high, low); a fourth and later ones repeat the cycle and may
+    share.  An exception in a thread is re-raised here."""
     import threading
 
     import torch
@@ -281,7 +284,13 @@ def run_concurrently(batches: list, fn, device=None) -> float:
     for k in range(len(batches)):
         key = (dev.index, k)
         if key not in _WORKER_STREAMS:
-            _WORKER_STREAMS[key] = torch.cuda.Stream(device=dev, priority=(-1 if k % 2 else 0))
+            with torch.cuda.device(dev):
+                least, greatest = C.c_int(), C.c_int()
+                L.check(L.lib().ldc_stream_priority_range(C.byref(least), C.byref(greatest)), "ldc_stream_priority_range")
+                levels = [0, greatest.value, least.value]               # normal, high, low
+                handle = C.c_void_p()
+                L.check(L.lib().ldc_stream_create(levels[k % 3], C.byref(handle)), "ldc_stream_create")
+            _WORKER_STREAMS[key] = torch.cuda.ExternalStream(handle.value, device=dev)      # kept for the process' life
         streams.append(_WORKER_STREAMS[key])
     errors = [None] * len(batches)
 

@@ -15,7 +15,7 @@ LIB_PATH = Path(os.environ.get("LDC_HIP_LIB", _PKG / "lib" / "libldc_hip.so"))
 
 REC_LEN, CTRL_LEN, SCAL_LEN, NPART = 8, 8, 8, 12
 SYNC_LEN, SYNC_GIVEUP = 128, 96
-ABI_VERSION = 4
+ABI_VERSION = 5
 PERSIST_AUTO_TILES = 0      # LDC_PERSIST_AUTO_TILES of include/ldc_hip.h (auto mode picks the persistent kernel up to here)
 PERSIST_XCD_TILES = 25      # LDC_PERSIST_XCD_TILES: mode 2 (all work-groups of a trial on one XCD) is available up to here
 PERSIST_AUTO_XCD_TILES = 0  # LDC_PERSIST_AUTO_XCD_TILES: auto mode picks mode 2 up to here
@@ -98,6 +98,9 @@ def lib() -> C.CDLL:
     L.ldc_pack.argtypes = [_dp, _dp, C.c_int, _dp]
     L.ldc_debug_ablate.argtypes = [_dp, C.c_int]
     L.ldc_debug_stamps.argtypes = [_dp, C.c_void_p]
+    L.ldc_stream_priority_range.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ldc_stream_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.ldc_stream_destroy.argtypes = [C.c_void_p]
     L.ldc_mfma_selftest.argtypes = [_dp, _dp, _dp, _dp]
     L.ldc_mfma_peak.argtypes = [_dp, C.c_int, C.c_int, _dp]
     for name in EXPORTS:
@@ -115,7 +118,7 @@ EXPORTS = (
     "ldc_residual_debug", "ldc_gemm_nt",
     "ldc_batch_workspace_bytes", "ldc_batch_create", "ldc_batch_destroy", "ldc_batch_enqueue",
     "ldc_poisson_fastdiag", "ldc_vortex_extrema", "ldc_mfma_selftest", "ldc_mfma_peak", "ldc_debug_ablate", "ldc_debug_stamps",
-    "ldc_pack",
+    "ldc_pack", "ldc_stream_priority_range", "ldc_stream_create", "ldc_stream_destroy",
 )
 
 

@@ -119,7 +119,7 @@ def farm_rate(N, B, device, dist, seconds=0.3):
               basis_type="chebyshev", CFL=1.5, beta_squared=5.0, corner_treatment="smoothing", multigrid="none",
               device=device, check_every=4096, graph_iters=64)
     trials = [dict(kw, Re=1000.0, corner_smoothing=0.02 + 0.01 * q) for q in range(B)]
-    n_streams = max(1, min(int(os.environ.get("LDC_BATCH_STREAMS", "2")), B))
+    n_streams = max(1, min(int(os.environ.get("LDC_BATCH_STREAMS", "3")), 2, B))      # one equal-N group: two halves
     cut = [(B * k) // n_streams for k in range(n_streams + 1)]
     halves = [BatchedSGSolver(trials[cut[k]:cut[k + 1]]) for k in range(n_streams)]
     run_concurrently(halves, lambda b: b.run_iterations(64, diagnostics=False), device)      # edge fix, graph build
@@ -332,7 +332,7 @@ def main():
         rates = dist.all_gather_object(rate)
         farm = {"value": float(sum(rates)), "unit": "trial-iterations/s", "n_gpus": world, "trials_per_gpu": fB, "N": fN,
                 "per_gpu": [float(r) for r in rates], "iterations_timed_per_trial": n_it,
-                "streams": max(1, min(int(os.environ.get("LDC_BATCH_STREAMS", "2")), fB)),
+                "streams": max(1, min(int(os.environ.get("LDC_BATCH_STREAMS", "3")), 2, fB)),
                 "workload": f"{fB} SG trials of N={fN} per GPU as main.py advances the trials a rank owns: two batches with "
                             "shared launches on two HIP streams (step()-only loop)"}
 

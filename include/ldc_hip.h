@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define LDC_ABI_VERSION 4
+#define LDC_ABI_VERSION 5
 
 #define LDC_E_ARG      (-1)  /* null pointer / inconsistent geometry */
 #define LDC_E_STATE    (-2)  /* handle not valid for the call */
@@ -263,6 +263,15 @@ int ldc_mfma_selftest(const double *A, const double *B, double *D, void *stream)
 /* fp64 MFMA issue-rate micro-benchmark: runs `iters` x 8 independent MFMAs per wave on    */
 /* every SIMD; returns nothing (time it with events); flops = grid*4*iters*8*2048          */
 int ldc_mfma_peak(double *sink, int iters, int grid, void *stream);
+
+/* worker streams for sweeps (solvers.spectral.batched.run_concurrently): a non-blocking HIP stream of the given   */
+/* priority on the current device.  HIP has three priority levels here (ldc_stream_priority_range: least 1,        */
+/* greatest -1), torch offers two of them; streams of DIFFERENT priority never share a hardware queue, which is     */
+/* what lets their launches overlap reliably.  The caller owns the stream (wrap it, e.g. torch.cuda.ExternalStream) */
+/* and destroys it when no work is pending on it.                                                                   */
+int ldc_stream_priority_range(int *least, int *greatest);
+int ldc_stream_create(int priority, void **stream);
+int ldc_stream_destroy(void *stream);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ def test_header_and_exports_agree(lib):
     L = lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ldc_version() == lib.ABI_VERSION == 4
+    assert L.ldc_version() == lib.ABI_VERSION == 5
 
 
 def test_python_constants_match_the_header(lib):
