@@ -208,3 +208,31 @@ def test_fsg_batches_on_two_streams_equal_stand_alone_solves():
         one.close()
     for b in halves:
         b.close()
+
+
+def test_worker_streams_come_in_three_priorities():
+    """The library hands out non-blocking streams of every priority level the hardware has (three here; torch offers
+    two); run_concurrently wraps them as torch streams, one per worker, and keeps them."""
+    import ctypes as C
+    import torch
+    from solvers.spectral import ldc_lib as L
+    from solvers.spectral import batched
+    lo, hi = C.c_int(), C.c_int()
+    assert L.lib().ldc_stream_priority_range(C.byref(lo), C.byref(hi)) == 0
+    assert lo.value > 0 > hi.value                         # least = 1, greatest = -1 on MI355X
+    assert L.lib().ldc_stream_create(0, None) == -1        # LDC_E_ARG
+    for prio in (lo.value, 0, hi.value):
+        h = C.c_void_p()
+        assert L.lib().ldc_stream_create(prio, C.byref(h)) == 0 and h.value
+        s = torch.cuda.ExternalStream(h.value)
+        with torch.cuda.stream(s):
+            x = torch.ones(1024, device="cuda").sum()
+        s.synchronize()
+        assert float(x) == 1024.0
+        assert L.lib().ldc_stream_destroy(h) == 0
+    seen = []
+    batched.run_concurrently([0, 1, 2], lambda k: seen.append((k, torch.cuda.current_stream().cuda_stream)))
+    assert len({ptr for _, ptr in seen}) == 3 and sorted(k for k, _ in seen) == [0, 1, 2]
+    again = []
+    batched.run_concurrently([0, 1, 2], lambda k: again.append((k, torch.cuda.current_stream().cuda_stream)))
+    assert dict(seen) == dict(again)                        # the same three streams every time
