@@ -46,3 +46,18 @@ def test_committed_bench_line_keeps_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and "sample" in c
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-6
+
+
+def test_one_batch_runs_in_the_callers_thread_without_a_gpu():
+    """run_concurrently with a single item is a plain call (LDC_BATCH_STREAMS=1, or a rank with one batch): no stream,
+    no thread, exceptions pass straight through."""
+    import sys
+    import threading
+    sys.path.insert(0, str(ROOT / "02689-advancednumericalalgorithmp3_amd" / "src"))
+    from solvers.spectral.batched import run_concurrently
+    seen = []
+    wall = run_concurrently(["only"], lambda b: seen.append((b, threading.current_thread() is threading.main_thread())))
+    assert seen == [("only", True)] and wall >= 0.0
+    import pytest
+    with pytest.raises(ZeroDivisionError):
+        run_concurrently(["x"], lambda b: 1 / 0)
