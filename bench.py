@@ -28,9 +28,10 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE J
               many regions there were, `launch_path` what the K iterations were enqueued as ("graph": hipGraph
               replays of captures of at most 64 iterations that divide K, "graph+eager" when K has a remainder,
               "persistent": one launch of the persistent trial kernel).
-* farm      : a second, sweep-shaped measurement for the multi-GPU runs -- every rank advances a BATCH of
-              `trials_per_gpu` equal-N trials with shared launches (what main.py does with the trials a rank owns
-              in the Hydra multirun / Optuna search), value = trial-iterations/s over all ranks.
+* farm      : a second, sweep-shaped measurement for the multi-GPU runs -- every rank advances `trials_per_gpu`
+              equal-N trials the way main.py advances the trials a rank owns in the Hydra multirun / Optuna search:
+              two batches with shared launches, side by side on two HIP streams of different priority;
+              value = trial-iterations/s over all ranks.
 """
 from __future__ import annotations
 
