@@ -1,6 +1,6 @@
 """Three worker streams on the three stream priorities HIP has (torch only offers two): trial-iterations per second of
 three single N=256 trials / three batches at N=128, against two streams (development aid).
-    python tools/ab_prio3.py N n_per_batch"""
+    python tools/ab_prio3.py N n_per_batch [n_batches=3]"""
 import ctypes
 import os
 import sys
@@ -13,6 +13,7 @@ from solvers.spectral.batched import BatchedSGSolver
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 b = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+nb = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 torch.cuda.init(); torch.zeros(1, device="cuda")
 path = [ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln][0]
 hip = ctypes.CDLL(path)                      # the copy torch has loaded, not a second runtime
@@ -42,7 +43,7 @@ def make(k):
     return x, (lambda: L.check(L.lib().ldc_batch_enqueue(x._batch, K, 1, L.stream_ptr())))
 
 
-objs = [make(k) for k in range(3)]
+objs = [make(k) for k in range(nb)]
 torch.cuda.synchronize()
 
 
@@ -60,8 +61,8 @@ def timed(streams, which):
 
 two = [stream(0), stream(hi.value)]
 three = [stream(lo.value), stream(0), stream(hi.value)]
-t1 = timed([torch.cuda.current_stream()], [0, 1, 2])
-t2 = timed(two, [0, 1, 2])
-t3 = timed(three, [0, 1, 2])
-print(f"N={N} 3 x {b} trial(s): one stream {3 * b * K / t1:9.0f}   two priorities {3 * b * K / t2:9.0f}   "
-      f"three priorities {3 * b * K / t3:9.0f} trial-it/s", flush=True)
+t1 = timed([torch.cuda.current_stream()], list(range(nb)))
+t2 = timed(two, list(range(nb)))
+t3 = timed(three, list(range(nb)))
+print(f"N={N} {nb} x {b} trial(s): one stream {nb * b * K / t1:9.0f}   two priorities {nb * b * K / t2:9.0f}   "
+      f"three priorities {nb * b * K / t3:9.0f} trial-it/s", flush=True)
