@@ -46,6 +46,16 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
+// Timing switches and cycle stamps (ldc_debug_ablate / ldc_debug_stamps) exist only in the INSTRUMENTED build of this
+// file (-DLDC_TIMING -> lib/libldc_hip_timing.so, what tools/kbench.py, kstamps.py, pstamps.py and ab_masks.py load).  In the
+// product library the argument blocks have no `ablate` field, LDC_ABL folds to 0 at compile time, the stamp macros are
+// empty and the two debug entry points return LDC_E_STATE.
+#ifdef LDC_TIMING
+#define LDC_ABL(x, bits) ((x).ablate & (bits))
+#else
+#define LDC_ABL(x, bits) 0
+#endif
+
 constexpr int kWaves = 4;          // waves per work-group == K-split factor
 constexpr int kThreads = 256;
 
@@ -329,8 +339,10 @@ struct StageArgs {
   const double* scal;
   int* ctrl;
   double* partials;
+#ifdef LDC_TIMING
   int ablate;                             // timing experiments only: 1 skip MFMAs, 2 skip operand loads,
                                           // 4 no stage-4 reduction, 8 no transposed stores, 16 no M-1 nodes, 32 no p store, 64 cycle stamps
+#endif
   double* dump[11];
   // packed twins (operand order, see ldpk): what the K loop reads / what the epilogue keeps in step
   int NB;
@@ -432,9 +444,13 @@ constexpr int kStageThreads = 64 * kStageWaves;
 // timing experiments (ldc_debug_stamps): cycle stamps per wave at fixed points of the stage kernel
 // (point 0 = kernel entry is taken unconditionally into t_entry and stored with point 1: a conditional store
 //  in the prologue would split the entry block, see tile_of_block)
+#ifdef LDC_TIMING
 #define LDC_STAMP(k) do { if ((a.ablate & 64) && lane == 0) { \
   double* st_ = a.dump[0] + ((size_t)bx * kStageWaves + wv) * 8; \
   st_[k] = (double)__builtin_amdgcn_s_memtime(); if ((k) == 1) st_[0] = (double)t_entry; } } while (0)
+#else
+#define LDC_STAMP(k) do { } while (0)
+#endif
 constexpr int kEdgeRowDoubles = 6 * 4 * 16;    // per wave: 6 rows of index M-1 x 4 groups x 16 (tail needs T <= 16)
 constexpr size_t kLdsLimit = 160 * 1024;
 
@@ -476,7 +492,9 @@ __device__ __forceinline__ double quad_sum(double x) {
 struct RoleOps {
   const double *A0, *A1, *B0, *B1, *A2, *B2;   // packed twins: the fragments of the K loop
   const double* row[6];                        // the row-major forms, slots A0 A1 A2 B0 B1 B2 (rows of index M-1)
+#ifdef LDC_TIMING
   int ablate;
+#endif
   int role; // 0: x-derivative chains, 1: y-derivative chains
   int x4;   // fifth contraction: 0: A2.B2 (grad p)   1: A0.B2 (d omega/dx = Dx . WT)   2: A2.B0 (d omega/dy = W . Dy)
 };
@@ -493,7 +511,7 @@ struct ExtraFrags {    // operands of the fifth contraction: single-buffered (lo
 // I, J: block row of the A / B operands; G: 16-k group
 template <bool COH>
 __device__ __forceinline__ void load_role(RoleFrags& f, const RoleOps& o, int NB, int I, int J, int G, int lane) {
-  const int keep = (o.ablate & 2) ? 0 : 1;
+  const int keep = LDC_ABL(o, 2) ? 0 : 1;
   I *= keep; J *= keep; G *= keep; lane *= keep;
   f.a0 = ldpk_t<COH>(o.A0, NB, I, G, lane); f.a1 = ldpk_t<COH>(o.A1, NB, I, G, lane);
   f.b0 = ldpk_t<COH>(o.B0, NB, J, G, lane); f.b1 = ldpk_t<COH>(o.B1, NB, J, G, lane);
@@ -501,7 +519,7 @@ __device__ __forceinline__ void load_role(RoleFrags& f, const RoleOps& o, int NB
 
 template <bool COH>
 __device__ __forceinline__ void load_extra(ExtraFrags& x, const RoleOps& o, int NB, int I, int J, int G, int lane) {
-  const int keep = (o.ablate & 2) ? 0 : 1;
+  const int keep = LDC_ABL(o, 2) ? 0 : 1;
   I *= keep; J *= keep; G *= keep; lane *= keep;
   // both, always: a load that only one role issues makes the number of loads in flight path-dependent, and the
   // compiler then waits with vmcnt(0) before every group's MFMAs (prefetch included).  The operand a role does
@@ -521,11 +539,15 @@ __device__ __forceinline__ void dma16(const double* src, double* lds_dst) {
 
 template <bool GP, int NA>
 __device__ __forceinline__ void mfma_role(const RoleFrags& f, const ExtraFrags& x, v4d (&acc)[NA], int ablate, int x4) {
+#ifdef LDC_TIMING
   if (ablate & 1) {   // keep the operands live without issuing MFMAs
     acc[0][0] += f.a0[0] + f.b0[1] + f.a1[2] + f.b1[3];
     if (GP) acc[4][0] += x.a2[0] + x.b2[0];
     return;
   }
+#else
+  (void)ablate;
+#endif
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     acc[0] = MFMA_F64(f.a0[s], f.b0[s], acc[0]);
@@ -674,7 +696,9 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
   using L = StageLds<GP, EDGES>;
   constexpr int NA = L::NA;
   double* red = lds;
+#ifdef LDC_TIMING
   const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int role = wv >> 2, kq = wv & 3;
@@ -688,14 +712,16 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
   //   row nodes (M-1, 16J + idx) need the B fragments of column block J  -> the diagonal tile (J, J)
   //   column nodes (16I + idx, M-1) need the A fragments of row block I  -> tile (I, I+1 mod T)
   //   the corner node needs no fragments                                 -> tile (0, 2) (T < 3: tile (0, 0))
-  const bool etile = EDGES && a.tail && !(a.ablate & 16);
+  const bool etile = EDGES && a.tail && !LDC_ABL(a, 16);
   const bool rowE = etile && (I == J);
   const bool colE = etile && (J == (I + 1) % T);
   const bool cornE = etile && (T >= 3 ? (I == 0 && J == 2) : (I == 0 && J == 0));
-  const bool anyE = (rowE || colE || cornE) && !(a.ablate & 512);     // block-uniform (512: timing, no K-loop part)
+  const bool anyE = (rowE || colE || cornE) && !LDC_ABL(a, 512);     // block-uniform (512: timing, no K-loop part)
 
   RoleOps o;
+#ifdef LDC_TIMING
   o.ablate = a.ablate;
+#endif
   o.role = role;
   o.x4 = (DIAG == 2) ? (role == 0 ? 1 : 2) : 0;
   if (role == 0) {
@@ -715,7 +741,7 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
   // they are then older than every fragment load, so waiting for a fragment never leaves one of them pending (issued
   // between the first fragments and the pointwise loads they made the compiler wait with vmcnt(0) before the MFMAs of
   // every group, prefetch included: the K loop lost its overlap)
-  if (anyE && !(a.ablate & 2048)) {      // (2048: timing, no LDS-direct rows)
+  if (anyE && !LDC_ABL(a, 2048)) {      // (2048: timing, no LDS-direct rows)
     const int h = lane & 1, q = (lane >> 1) & 3, gi = (lane >> 3) & 3, sl = lane >> 5;
     const size_t off = (size_t)m1 * LD + 16 * (kq + 4 * gi) + 4 * q + 2 * h;
     const bool live = (kq + 4 * gi) < T;
@@ -747,7 +773,7 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
   const int ti = 4 * (wv & 3) + (lane >> 4), tj = lane & 15;
   const bool owner = tid < 256;
   const int ekind = (tid - 256) >> 4, eidx = (tid - 256) & 15;
-  const bool edge_thr = !owner && !(a.ablate & 1024) &&     // (1024: timing, no epilogue part)
+  const bool edge_thr = !owner && !LDC_ABL(a, 1024) &&     // (1024: timing, no epilogue part)
                         ((ekind == 0 && rowE) || (ekind == 1 && colE) || (ekind == 2 && eidx == 0 && cornE));
   const int i = owner ? (r0 + ti) : ((ekind == 1) ? (r0 + eidx) : m1);
   const int j = owner ? (c0 + tj) : ((ekind == 0) ? (c0 + eidx) : m1);
@@ -816,13 +842,17 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
   for (int n = 0; n < ng; n += 2) {
     if (GP) load_extra<false>(fx, o, NB, I, J, gk(n), lane);          // first: loads return in issue order
     load_role<false>(fb, o, NB, I, J, gk(n + 1 < ng ? n + 1 : n), lane);   // clamped: harmless reload
-    mfma_role<GP, NA>(fa, fx, acc, a.ablate, o.x4);
-    if (anyE && !(a.ablate & 4096)) edge_group<VEL, GP>(ea, fa, fx, o, erow, n, lane, rowE, colE, cornE);
+    // the prefetch stays IN FRONT of this group's MFMAs: without the branches of the timing switches around them
+    // (product build) hipcc sinks the eight loads behind the sixteen MFMAs and the next group waits with vmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_role<GP, NA>(fa, fx, acc, LDC_ABL(a, ~0), o.x4);
+    if (anyE && !LDC_ABL(a, 4096)) edge_group<VEL, GP>(ea, fa, fx, o, erow, n, lane, rowE, colE, cornE);
     if (n + 1 < ng) {
       if (GP) load_extra<false>(fx, o, NB, I, J, gk(n + 1), lane);
       load_role<false>(fa, o, NB, I, J, gk(n + 2 < ng ? n + 2 : n + 1), lane);
-      mfma_role<GP, NA>(fb, fx, acc, a.ablate, o.x4);
-      if (anyE && !(a.ablate & 4096)) edge_group<VEL, GP>(ea, fb, fx, o, erow, n + 1, lane, rowE, colE, cornE);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_role<GP, NA>(fb, fx, acc, LDC_ABL(a, ~0), o.x4);
+      if (anyE && !LDC_ABL(a, 4096)) edge_group<VEL, GP>(ea, fb, fx, o, erow, n + 1, lane, rowE, colE, cornE);
     }
   }
 
@@ -937,7 +967,7 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
         st_out(a.Uout + ij, un, a.wt);
         st_out(a.Vout + ij, vn, a.wt);
       }
-      if (a.Pout != nullptr && !(a.ablate & 32)) {
+      if (a.Pout != nullptr && !LDC_ABL(a, 32)) {
         const double pn = interior ? nm_madd(adt, Rp, p0) : 0.0;
         st_out(a.Pout + ij, pn, a.wt);
         tp[ti * 17 + tj] = pn;
@@ -970,7 +1000,7 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
   LDC_STAMP(4);
   __syncthreads();
   LDC_STAMP(5);
-  if (owner && !(a.ablate & 8)) {
+  if (owner && !LDC_ABL(a, 8)) {
     const int tr = tid >> 4, tc = tid & 15;   // write UT[c0+tr][r0+tc] = tile[tc][tr]
     const size_t ot = (size_t)(c0 + tr) * LD + r0 + tc;
     if (a.rm_out) {
@@ -988,7 +1018,7 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
       if (DIAG == 1) { st_out2(a.WK + kb, tw[e], tw[e + 1], a.wt); st_out2(a.WTK + kbT, tw[eT], tw[eT + 17], a.wt); }
     } else {
       st_out2(a.VoutK + kb, tv[e], tv[e + 1], a.wt); st_out2(a.VoutTK + kbT, tv[eT], tv[eT + 17], a.wt);
-      if (a.Pout != nullptr && !(a.ablate & 32)) st_out2(a.PoutK + kb, tp[e], tp[e + 1], a.wt);
+      if (a.Pout != nullptr && !LDC_ABL(a, 32)) st_out2(a.PoutK + kb, tp[e], tp[e + 1], a.wt);
     }
   }
   if (DIAG != 0) {
@@ -1008,7 +1038,7 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
       a.ctrl[LDC_CTRL_DROWS] = nblk;
     }
   }
-  if (LAST && !(a.ablate & 4)) {
+  if (LAST && !LDC_ABL(a, 4)) {
     // block reduction through LDS (the accumulator region is free again): one wave per value,
     // fixed order; ten shuffle trees per wave would cost far more than this transpose
 #pragma unroll
@@ -1624,8 +1654,12 @@ __device__ __forceinline__ void tile_setup(TileCtx& c, const StageArgs& a, int b
 template <bool GPV, bool LAST, int DIAG>
 __device__ __forceinline__ void tile_stage(TileCtx& c, const StageArgs a, double* lds, const int bx, const int step0,
                                            const double dt, double* stp) {
+#ifdef LDC_TIMING
 #define LDC_PSTAMP(k) do { if (stp != nullptr && c.lane == 0) \
     stp[((size_t)bx * kStageWaves + c.wv) * 8 + (k)] = (double)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LDC_PSTAMP(k) do { (void)stp; (void)bx; } while (0)
+#endif
   LDC_PSTAMP(0);
   constexpr bool GP = GPV || (DIAG == 2);
   static_assert(!(GPV && DIAG == 2), "stage 2 of SG carries no pressure contraction");
@@ -1642,7 +1676,9 @@ __device__ __forceinline__ void tile_stage(TileCtx& c, const StageArgs a, double
   const double adt = a.alpha * dt;
 
   RoleOps o;
+#ifdef LDC_TIMING
   o.ablate = 0;
+#endif
   o.role = role;
   o.x4 = (DIAG == 2) ? (role == 0 ? 1 : 2) : 0;
   if (role == 0) {
@@ -1955,9 +1991,17 @@ __global__ __launch_bounds__(kStageThreads, 2) void trial_kernel(const TrialArgs
     if (bx < 0) return;
   }
   // timing experiments: cycle stamps (s_memtime) of the LAST iteration's phase boundaries, thread 0 of every work-group
+#ifdef LDC_TIMING
   double* const stamps = LDC_TRIAL_ARG(double*, stamps);
+#else
+  double* const stamps = nullptr;
+#endif
+#ifdef LDC_TIMING
 #define LDC_TSTAMP(k) do { if (stamps != nullptr && tid == 0 && it == n_iters - 1) \
     stamps[(size_t)bx * 64 + (k)] = (double)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LDC_TSTAMP(k) do { } while (0)
+#endif
   {
     const FinalArgs fa = LDC_TRIAL_ARG(FinalArgs, post.fin);
     if (tid == 0) {
@@ -2341,8 +2385,12 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 // write-through stores (st_out); ldc_debug_ablate bits 128 / 256 force plain / write-through for A/B timing
 // (tiles = work-groups of 16 x 16 nodes in the launch, all trials of a batch together)
 int write_through_policy(const ldc_solver* s, int tiles) {
+#ifdef LDC_TIMING
   if (s->ablate & 128) return 0;
   if (s->ablate & 256) return 1;
+#else
+  (void)s;
+#endif
   return tiles >= LDC_WT_MIN_TILES ? 1 : 0;
 }
 
@@ -2364,10 +2412,13 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
   a.W = p.W; a.WT = p.WT;
   a.partZ0 = p.partials + p.partials_stride; a.partP0 = p.partials + 3 * p.partials_stride;
   a.stride = p.partials_stride;
-  a.ablate = s->stamps ? s->ablate : (s->ablate & ~64);
   a.wt = write_through_policy(s, s->nt);
-  a.rm_out = (k == 3 && !(s->ablate & 16384)) ? 1 : 0;      // (16384: timing, stage 4 without its row-major velocity stores)
+  a.rm_out = (k == 3) ? 1 : 0;
+#ifdef LDC_TIMING
+  a.ablate = s->stamps ? s->ablate : (s->ablate & ~64);
+  if (s->ablate & 16384) a.rm_out = 0;     // (16384: timing, stage 4 without its row-major velocity stores)
   a.dump[0] = s->stamps;
+#endif
   // ping-pong: 0: S0 -> A, 1: A -> B, 2: B -> A, 3: A -> S0 (in place)
   const double *in[4][4] = {{p.U, p.UT, p.V, p.VT}, {p.UA, p.UAT, p.VA, p.VAT},
                             {p.UB, p.UBT, p.VB, p.VBT}, {p.UA, p.UAT, p.VA, p.VAT}};
@@ -2589,7 +2640,9 @@ TrialArgs make_trial_args(const ldc_solver* s, int n_iters, int with_diag) {
   for (int k = 0; k < 4; ++k) {
     ta.st[k] = make_stage_args(s, k);
     ta.st[k].wt = 1;              // every store of state is write-through: it is what publishes it
+#ifdef LDC_TIMING
     ta.st[k].ablate = 0;
+#endif
   }
   int grid = 0;
   ta.post = make_post_args(s, s->p.P, 0, 1, with_diag, &grid);
@@ -2852,16 +2905,35 @@ int ldc_solver_status(ldc_solver* s) {
   return flag ? LDC_E_SYNC : 0;
 }
 
+// timing experiments: only the instrumented build (-DLDC_TIMING) has the switches; the product library refuses
 int ldc_debug_ablate(ldc_solver* s, int mask) {
+#ifdef LDC_TIMING
   if (!s) return LDC_E_STATE;
   s->ablate = mask;
   return 0;
+#else
+  (void)s; (void)mask;
+  return LDC_E_STATE;
+#endif
 }
 
 int ldc_debug_stamps(ldc_solver* s, double* buf) {
+#ifdef LDC_TIMING
   if (!s) return LDC_E_STATE;
   s->stamps = buf;
   return 0;
+#else
+  (void)s; (void)buf;
+  return LDC_E_STATE;
+#endif
+}
+
+int ldc_timing_build(void) {
+#ifdef LDC_TIMING
+  return 1;
+#else
+  return 0;
+#endif
 }
 
 int ldc_stage(ldc_solver* s, int k, void* stream) {

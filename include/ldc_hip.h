@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define LDC_ABI_VERSION 5
+#define LDC_ABI_VERSION 6
 
 #define LDC_E_ARG      (-1)  /* null pointer / inconsistent geometry */
 #define LDC_E_STATE    (-2)  /* handle not valid for the call */
@@ -247,15 +247,20 @@ int ldc_poisson_fastdiag(const double *Qx, const double *Qxinv, const double *Qy
 int ldc_vortex_extrema(const double *Psi, const double *W, const double *x, const double *y,
                        int M, int LD, double *out_val, int32_t *out_idx, void *stream);
 
-/* timing experiments only (results are WRONG while bits 0-5 are set): bit 0 skips the MFMAs, bit 1 the   */
-/* operand loads of the stage kernel; bits 7 / 8 (128 / 256) force plain / write-through state stores       */
-/* (results stay right; takes effect for launches and graphs built afterwards)                              */
-/* bits 4 / 9-12 (16 / 512, 1024, 2048, 4096) switch parts of the index-(M-1) jobs off: all / K-loop part /     */
-/* epilogue part / LDS-direct rows / per-group dot products (the recorded |R|, Z, P then miss those nodes)        */
+/* Timing experiments.  The switches exist only in the INSTRUMENTED build of the library (csrc/ldc_kernels.hip       */
+/* compiled with -DLDC_TIMING -> lib/libldc_hip_timing.so, loaded by tools/kbench.py, kstamps.py, pstamps.py,          */
+/* ab_masks.py); in the product library the kernels carry no switch and both calls return LDC_E_STATE.                 */
+/* ldc_timing_build() says which build is loaded (1 instrumented, 0 product).                                          */
+/* Instrumented build: results are WRONG while bits 0-5 are set: bit 0 skips the MFMAs, bit 1 the operand loads of    */
+/* the stage kernel; bits 7 / 8 (128 / 256) force plain / write-through state stores (results stay right; takes       */
+/* effect for launches and graphs built afterwards); bits 4 / 9-12 (16 / 512, 1024, 2048, 4096) switch parts of the   */
+/* index-(M-1) jobs off: all / K-loop part / epilogue part / LDS-direct rows / per-group dot products (the recorded    */
+/* |R|, Z, P then miss those nodes)                                                                                    */
 int ldc_debug_ablate(ldc_solver *s, int mask);
-/* Timing experiments: with mask bit 64 set every wave of the stage kernel writes seven cycle stamps
+/* Instrumented build: with mask bit 64 set every wave of the stage kernel writes seven cycle stamps
  * (s_memtime) to buf[((block * 8 + wave) * 8 + point)]; buf holds T*T*64 doubles.  NULL switches off. */
 int ldc_debug_stamps(ldc_solver *s, double *buf);
+int ldc_timing_build(void);
 
 /* hardware self-test: D = A(16x4) * B(4x16) with the f64 MFMA; used by tests to pin the  */
 /* operand / result lane maps                                                             */

@@ -430,6 +430,28 @@ def fft_prolongation_matrix(nc: int, nf: int) -> np.ndarray:
     return ev @ coeff
 
 
+def polynomial_prolongation_matrix(nc: int, nf: int) -> np.ndarray:
+    """(nf, nc) matrix of the reference's ``PolynomialProlongation.prolongate_1d``
+    (operators/transfer_operators.py:333-376): the degree-(nc-1) Chebyshev interpolant of the coarse CGL data
+    evaluated on the fine CGL nodes.  The reference fits with ``chebfit`` on cos(pi k / N) (descending); index k
+    of the coarse grid maps to index i of the fine grid the same way on the ascending nodes used here (mirror
+    symmetry), so the matrix is the same."""
+    if nc == nf:
+        return np.eye(nc)
+    xc = np.cos(np.pi * np.arange(nc) / (nc - 1))
+    xf = np.cos(np.pi * np.arange(nf) / (nf - 1))
+    return chebvander(xf, nc - 1) @ np.linalg.solve(chebvander(xc, nc - 1), np.eye(nc))
+
+
+def prolongation_matrix(method: str, nc: int, nf: int) -> np.ndarray:
+    """create_transfer_operators (operators/transfer_operators.py:503-529)."""
+    if method == "fft":
+        return fft_prolongation_matrix(nc, nf)
+    if method == "polynomial":
+        return polynomial_prolongation_matrix(nc, nf)
+    raise ValueError(f"Unknown prolongation method: {method}")
+
+
 def fsg_orders(n_fine: int, n_levels: int, coarsest_n: int = 12) -> list:
     """Polynomial orders coarse -> fine (multigrid/fsg.py:517-531)."""
     orders, n = [], n_fine
@@ -441,12 +463,12 @@ def fsg_orders(n_fine: int, n_levels: int, coarsest_n: int = 12) -> list:
     return orders[::-1]
 
 
-def fsg_prolongate(coarse: "OracleSG", fine: "OracleSG", lid_velocity: float):
+def fsg_prolongate(coarse: "OracleSG", fine: "OracleSG", lid_velocity: float, method: str = "fft"):
     """multigrid/fsg.py:551-614 including quirk Q2: the boundary re-imposition uses [ix, iy]
     arrays as if they were [iy, ix], so the EAST wall gets the (scalar) lid speed and the lid
     row is zeroed; the caller's initialize_lid then restores the lid column."""
-    Pf = fft_prolongation_matrix(coarse.M, fine.M)
-    Pi = fft_prolongation_matrix(coarse.Mi, fine.Mi)
+    Pf = prolongation_matrix(method, coarse.M, fine.M)
+    Pi = prolongation_matrix(method, coarse.Mi, fine.Mi)
     u = Pf @ coarse.u @ Pf.T
     v = Pf @ coarse.v @ Pf.T
     u[0, :] = 0.0; v[0, :] = 0.0
@@ -458,7 +480,7 @@ def fsg_prolongate(coarse: "OracleSG", fine: "OracleSG", lid_velocity: float):
 
 
 def oracle_fsg(N, Re, *, tolerance=1e-6, max_iterations=500000, n_levels=2, coarse_tolerance_factor=1.0,
-               **kw):
+               prolongation_method="fft", **kw):
     """``solve_fsg`` (multigrid/fsg.py:1053-1221): coarse -> fine, the smoother differentiates the
     STAGE pressure, no warm-up, NaN/Inf exit.  Returns (finest level, total iterations, converged)."""
     orders = fsg_orders(N, n_levels)
@@ -470,7 +492,7 @@ def oracle_fsg(N, Re, *, tolerance=1e-6, max_iterations=500000, n_levels=2, coar
         if idx == 0:
             lvl.u[:] = 0.0; lvl.v[:] = 0.0; lvl.p[:] = 0.0
         else:
-            fsg_prolongate(levels[idx - 1], lvl, U)
+            fsg_prolongate(levels[idx - 1], lvl, U, prolongation_method)
         lvl.u[:, -1] = lvl.u_lid                       # initialize_lid (:950-954)
         lvl.v[:, -1] = 0.0
         converged = False

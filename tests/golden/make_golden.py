@@ -361,6 +361,10 @@ def g8_fsg(full=False):
         out[f"pro_in_{nc}_{nf}"] = f
         out[f"pro_out_{nc}_{nf}"] = pro.prolongate_2d(f, (nf, nf))
         out[f"pro_mat_{nc}_{nf}"] = np.stack([pro.prolongate_1d(e, nf) for e in np.eye(nc)], axis=1)
+    poly = tr.PolynomialProlongation()                  # prolongation_method="polynomial" (transfer_operators.py:333-376)
+    for nc, nf in ((17, 33), (15, 31), (9, 19)):
+        out[f"poly_mat_{nc}_{nf}"] = np.stack([poly.prolongate_1d(e, nf) for e in np.eye(nc)], axis=1)
+        out[f"poly_out_{nc}_{nf}"] = poly.prolongate_2d(out[f"pro_in_{nc}_{nf}"], (nf, nf))
     np.savez_compressed(OUT / "g8_prolongation.npz", **out)
 
     runs = {}
@@ -368,10 +372,23 @@ def g8_fsg(full=False):
              ("cap200_N24_Re400", 24, 400.0, dict(max_iterations=200, corner_smoothing=0.1)),
              ("single_N20_Re100", 20, 100.0, dict(max_iterations=250)),
              ("cap150_N48_Re1000_saad", 48, 1000.0, dict(max_iterations=150, corner_treatment="saad")),
-             ("lvl3_N48_Re100", 48, 100.0, dict(max_iterations=120, n_levels=3, coarse_tolerance_factor=10.0))]
+             ("lvl3_N48_Re100", 48, 100.0, dict(max_iterations=120, n_levels=3, coarse_tolerance_factor=10.0)),
+             # round 3: a two-level run whose coarse level is N=32 and fine level N=64 (tail layout on both), and the
+             # reference's other prolongation (create_transfer_operators, transfer_operators.py:526-527)
+             ("cap100_N64_Re1000", 64, 1000.0, dict(max_iterations=100)),
+             ("poly_cap200_N32_Re400", 32, 400.0, dict(max_iterations=200, prolongation_method="polynomial"))]
     if full:
         cases.append(("full_N32_Re100", 32, 100.0, dict()))
     meta = {}
+    # entries this call does not regenerate (the converged run without --full) are carried over from the committed files
+    if (OUT / "g8_fsg_runs.npz").exists():
+        names = {c[0] for c in cases}
+        old_meta = json.loads((OUT / "g8_fsg_runs.json").read_text())
+        with np.load(OUT / "g8_fsg_runs.npz") as old:
+            for key in old.files:
+                if key.rsplit("_", 1)[0] not in names:
+                    runs[key] = old[key]
+        meta.update({k: v for k, v in old_meta.items() if k not in names})
     for name, N, Re, kw in cases:
         t0 = time.time()
         with kron_guard():

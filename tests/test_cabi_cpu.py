@@ -25,7 +25,20 @@ def test_header_and_exports_agree(lib):
     L = lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ldc_version() == lib.ABI_VERSION == 5
+    assert L.ldc_version() == lib.ABI_VERSION == 6
+
+
+def test_product_library_has_no_timing_switches(lib):
+    """The timing switches (ldc_debug_ablate / ldc_debug_stamps) are compiled out of the product library; the
+    instrumented build (-DLDC_TIMING, tools/ only) is a file of its own and says so."""
+    L = lib.lib()
+    assert L.ldc_timing_build() == 0
+    fake = C.c_void_p(1)                                  # never dereferenced by the product build
+    assert L.ldc_debug_ablate(fake, 3) == -2 and L.ldc_debug_stamps(fake, None) == -2      # LDC_E_STATE
+    assert lib.TIMING_LIB_PATH.exists() and lib.TIMING_LIB_PATH != lib.LIB_PATH
+    T = C.CDLL(str(lib.TIMING_LIB_PATH))
+    assert T.ldc_timing_build() == 1 and T.ldc_version() == lib.ABI_VERSION
+    assert T.ldc_debug_ablate(None, 0) == -2              # a null handle is still refused there
 
 
 def test_python_constants_match_the_header(lib):

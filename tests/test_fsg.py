@@ -36,7 +36,19 @@ def test_prolongation_matrix_matches_reference(golden_dir, nc, nf):
         prolongation_matrix("spline", nc, nf)
 
 
-CAPPED = ["cap300_N32_Re100", "cap200_N24_Re400", "single_N20_Re100", "cap150_N48_Re1000_saad", "lvl3_N48_Re100"]
+@pytest.mark.parametrize("nc,nf", [(17, 33), (15, 31), (9, 19)])
+def test_polynomial_prolongation_matches_reference(golden_dir, nc, nf):
+    """prolongation_method="polynomial" (reference PolynomialProlongation, transfer_operators.py:333-376, chosen
+    at :526-527): product matrix and oracle matrix against the reference's own chebfit / chebval operator."""
+    g = np.load(golden_dir / "g8_prolongation.npz")
+    for P in (prolongation_matrix("polynomial", nc, nf), orc.polynomial_prolongation_matrix(nc, nf)):
+        assert np.max(np.abs(P - g[f"poly_mat_{nc}_{nf}"])) < 2e-12
+        got = P @ g[f"pro_in_{nc}_{nf}"] @ P.T
+        assert np.max(np.abs(got - g[f"poly_out_{nc}_{nf}"])) < 2e-11
+
+
+CAPPED = ["cap300_N32_Re100", "cap200_N24_Re400", "single_N20_Re100", "cap150_N48_Re1000_saad", "lvl3_N48_Re100",
+          "cap100_N64_Re1000", "poly_cap200_N32_Re400"]
 
 
 @pytest.mark.parametrize("name", CAPPED)
@@ -46,7 +58,7 @@ def test_oracle_fsg_capped_runs(runs, name):
     Numba kernels are fastmath; tolerance 1e-10."""
     g, meta = runs
     c = meta[name]
-    kw = {k: v for k, v in c["kw"].items() if k in ("corner_smoothing", "corner_treatment")}
+    kw = {k: v for k, v in c["kw"].items() if k in ("corner_smoothing", "corner_treatment", "prolongation_method")}
     lvl, total, conv = orc.oracle_fsg(c["N"], c["Re"], max_iterations=c["kw"]["max_iterations"],
                                       n_levels=c["kw"].get("n_levels", 2),
                                       coarse_tolerance_factor=c["kw"].get("coarse_tolerance_factor", 1.0), **kw)
@@ -109,17 +121,68 @@ def test_gpu_fsg_converged_run(runs):
     assert m.psi_min == pytest.approx(ref["psi_min"], rel=1e-6)
 
 
+def oracle_records(o, K):
+    """K iterations of the oracle with every history column the device records (include/ldc_hip.h LDC_REC_*):
+    rel change (base.py:250-258), |R_u|, |R_v|, |R_p| of the last stage (sg.py:463-473), E (sg.py:495-508), dt."""
+    rows = np.zeros((K, 8))
+    for k in range(K):
+        up, vp = o.u.copy(), o.v.copy()
+        dt = o.step()
+        du = np.linalg.norm(o.u - up) / (np.linalg.norm(up) + 1e-12)
+        dv = np.linalg.norm(o.v - vp) / (np.linalg.norm(vp) + 1e-12)
+        ru, rv, rp = o.residual_norms()
+        rows[k] = (max(du, dv), ru, rv, rp, o.energy(), 0.0, 0.0, dt)
+    return rows
+
+
 @pytest.mark.gpu
-def test_gpu_smoother_matches_oracle_stage_pressure():
-    """One level in smoother mode (stage pressure) against the oracle's stage_pressure=True steps."""
+@pytest.mark.parametrize("N,K", [(32, 200), (64, 200), (128, 100), (256, 25)])
+def test_gpu_smoother_matches_oracle_stage_pressure(N, K):
+    """One level in smoother mode (stage_pressure=1: a fifth contraction in EVERY stage, a transform launch between
+    the stages) against the oracle's stage_pressure=True steps -- at the sizes BASELINE config 5 runs (levels 64 and
+    128: T = 4 and 8, tail layout, XCD-patched tile order) and at N = 256.  Every history column, not only the
+    state."""
     from solvers.spectral.sg import SGSolver
-    N, Re, K = 32, 1000.0, 200           # SG diverges here with CFL 1.5 (quirk Q1); the smoother does not
+    Re = 1000.0                          # SG diverges at N=32 with CFL 1.5 (quirk Q1); the smoother does not
     s = SGSolver(name="spectral", Re=Re, nx=N, ny=N, basis_type="chebyshev", CFL=1.5, check_every=256, graph_iters=8)
     s._stage_pressure, s._warmup, s._nan_exit = 1, 0, True
     rec = s.run_iterations(K, diagnostics=False)
     o = orc.OracleSG(N, Re, stage_pressure=True)
-    dts = [o.step() for _ in range(K)]
+    ref = oracle_records(o, K)
     assert rec.shape[0] == K and np.all(np.isfinite(rec[:, 0]))
     assert np.max(np.abs(s.arrays.u.reshape(N + 1, N + 1) - o.u)) < 1e-11
+    assert np.max(np.abs(s.arrays.v.reshape(N + 1, N + 1) - o.v)) < 1e-11
     assert np.max(np.abs(s.arrays.p.reshape(N - 1, N - 1) - o.p)) < 1e-11
-    assert np.max(np.abs(rec[:, 7] - np.array(dts)) / np.array(dts)) < 1e-12
+    assert np.max(np.abs(rec[:, 7] - ref[:, 7]) / ref[:, 7]) < 1e-12
+    for col, name in ((0, "rel"), (1, "|R_u|"), (2, "|R_v|"), (3, "|R_p|"), (4, "E")):
+        assert np.max(np.abs(rec[:, col] - ref[:, col]) / np.abs(ref[:, col])) < 1e-10, name
+    s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_config5_shape_batched_fsg_vs_oracle():
+    """BASELINE config 5's own shape: eight FSG trials at N=128 (levels 64 -> 128) with different corner_smoothing,
+    advanced as main.py advances them -- two batches of four with shared launches, side by side on two HIP
+    streams -- capped at 150 iterations per level.  The first and the last trial against the oracle's FSG sequence
+    on the same corner_smoothing: iteration counts exactly, fields <= 1e-10 (reference multigrid/fsg.py:551-614
+    prolongation incl. quirk Q2, :857-995 smoother)."""
+    from solvers.spectral.batched import BatchedFSGSolver, solve_concurrently
+    cs = [0.02 + 0.011 * q for q in range(8)]
+    base = dict(name="spectral_fsg", Re=1000.0, lid_velocity=1.0, Lx=1.0, Ly=1.0, nx=128, ny=128, tolerance=1e-6,
+                max_iterations=150, basis_type="chebyshev", CFL=1.5, beta_squared=5.0, corner_treatment="smoothing",
+                multigrid="fsg", n_levels=2, coarse_tolerance_factor=1.0, prolongation_method="fft",
+                restriction_method="fft", check_every=64, graph_iters=16)
+    trials = [dict(base, corner_smoothing=c) for c in cs]
+    halves = [BatchedFSGSolver(trials[:4]), BatchedFSGSolver(trials[4:])]
+    assert halves[0].orders == [64, 128]
+    solve_concurrently(halves)
+    solvers = halves[0].solvers + halves[1].solvers
+    for q in (0, 7):
+        lvl, total, conv = orc.oracle_fsg(128, 1000.0, max_iterations=150, corner_smoothing=cs[q])
+        s = solvers[q]
+        assert s.metrics.iterations == total == 300 and s.metrics.converged == conv
+        assert np.max(np.abs(s.arrays.u.reshape(129, 129) - lvl.u)) < 1e-10
+        assert np.max(np.abs(s.arrays.v.reshape(129, 129) - lvl.v)) < 1e-10
+        assert np.max(np.abs(s.arrays.p.reshape(127, 127) - lvl.p)) < 1e-10
+    for b in halves:
+        b.close()

@@ -2,6 +2,8 @@
 (development aid)"""
 import os, sys, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "02689-advancednumericalalgorithmp3_amd", "src"))
+if "AB_ABLATE" in os.environ:      # the switches live in the instrumented build only (-DLDC_TIMING)
+    os.environ.setdefault("LDC_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "02689-advancednumericalalgorithmp3_amd", "lib", "libldc_hip_timing.so"))
 import torch
 from solvers.spectral import ldc_lib as L
 from solvers.spectral.batched import BatchedSGSolver

@@ -4,6 +4,8 @@ purpose).    python tools/ab_masks.py 0 16 1 2 3 ..."""
 import os
 import sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "02689-advancednumericalalgorithmp3_amd", "src"))
+# timing switches live in the instrumented build only (-DLDC_TIMING, built by __graft_entry__.build())
+os.environ.setdefault("LDC_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "02689-advancednumericalalgorithmp3_amd", "lib", "libldc_hip_timing.so"))
 import torch
 from solvers.spectral import ldc_lib as L
 from solvers.spectral.sg import SGSolver

@@ -13,6 +13,8 @@ ROOT = Path(__file__).resolve().parent.parent
 for p in (str(ROOT), str(ROOT / "02689-advancednumericalalgorithmp3_amd" / "src")):
     sys.path.insert(0, p)
 
+# timing switches live in the instrumented build only (-DLDC_TIMING, built by __graft_entry__.build())
+os.environ.setdefault("LDC_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "02689-advancednumericalalgorithmp3_amd", "lib", "libldc_hip_timing.so"))
 import torch  # noqa: E402
 
 import __graft_entry__ as g  # noqa: E402
