@@ -31,7 +31,7 @@ sys.path.insert(0, str(HERE / "src"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 from utilities.config import compose as C            # noqa: E402
-from utilities.sweep.farm import Dist, FarmError, TPESampler, run_farm  # noqa: E402
+from utilities.sweep.farm import Dist, FarmError, TPESampler, plan_rounds, run_farm, trial_cost  # noqa: E402
 
 log = logging.getLogger("main")
 
@@ -132,9 +132,11 @@ def run_batches(groups: list, device: str = None) -> list:
             parts = len(cfgs)
         cut = [(len(cfgs) * k) // parts for k in range(parts + 1)]
         for k in range(parts):
-            tasks.append(((cut[k + 1] - cut[k]) * float(cfgs[0]["N"]) ** 5, gi, cut[k], cut[k + 1]))
+            weight = max(trial_cost(dict(N=c["N"], Re=c["Re"]), solver=c["solver"].get("_target_", "")) for c in cfgs[cut[k]:cut[k + 1]])
+            tasks.append((weight, gi, cut[k], cut[k + 1]))      # a batch lasts as long as its longest trial
     tasks.sort(key=lambda t: (-t[0], t[1], t[2]))
     n_tasks = len(tasks)
+    n_threads = max(1, min(n_workers, n_tasks))
     lock, done = threading.Lock(), {}
 
     def worker(_):
@@ -150,6 +152,11 @@ def run_batches(groups: list, device: str = None) -> list:
                     node = {k: v for k, v in cfg["solver"].items() if k != "_target_"}
                     if device is not None:
                         node["device"] = device
+                    if n_threads > 1 and "persistent" in node:
+                        # a persistent launch needs all its work-groups co-resident; two of them dispatching from two
+                        # worker streams can each hold part of the CUs (or of the elected XCD) and spin until the
+                        # bounded wait gives up (LDC_E_SYNC).  Pool trials therefore run launch by launch.
+                        node["persistent"] = 0
                     nodes.append(node)
                 fsg = part[0]["solver"]["_target_"].endswith("FSGSolver")
                 if len(nodes) == 1:                 # alone on its stream: the single-trial kernels (no argument blocks in memory)
@@ -163,7 +170,6 @@ def run_batches(groups: list, device: str = None) -> list:
                 done[(gi, lo)] = exc
 
     t0 = time.perf_counter()
-    n_threads = max(1, min(n_workers, n_tasks))
     wall = run_concurrently(list(range(n_threads)), worker, device)
     good = [b for b in done.values() if not isinstance(b, Exception)]
     busy = sum(b.batch_seconds for b in good)
@@ -347,7 +353,13 @@ def main(argv=None) -> float | None:
                     where.append(part)
             else:
                 for q in members:
-                    out[q] = run_solver(cfgs[q], root_dir / str(offset + items[q][0]), device=device)
+                    # one failing trial (an FV solver error, an LdcError, ...) costs its own record only: the other
+                    # trials of this rank, finished or still to run, keep theirs (the farm's contract)
+                    try:
+                        out[q] = run_solver(cfgs[q], root_dir / str(offset + items[q][0]), device=device)
+                    except Exception as exc:
+                        log.exception("trial %d failed", offset + items[q][0])
+                        out[q] = dict(error=repr(exc), objective=math.inf)
         if groups:          # all batches of this rank through ONE pool of streams: sizes overlap too
             for part, recs in zip(where, run_batches(groups, device)):
                 for q, r in zip(part, recs):
@@ -371,6 +383,11 @@ def main(argv=None) -> float | None:
                 _TRACKER.parent_for(job_cfg(a, offset + i))
         _TRACKER.adopt(dist.all_gather_object(_TRACKER.parents if dist.rank == 0 else {})[0])
 
+    solver_hint = str((stamp_cfg.get("solver") or {}).get("_target_", ""))
+
+    def cost_of(trial):          # expected GPU seconds (measured iteration counts x time per iteration, by solver class)
+        return trial_cost(dict({"Re": stamp_cfg.get("Re", 100)}, **trial), solver=solver_hint)
+
     global _TRACKER
     _TRACKER = None
     if multirun:
@@ -385,35 +402,46 @@ def main(argv=None) -> float | None:
         trials = [dict(a, N=dict(a).get("N", base_cfg.get("N", 32)), _job=i) for i, a in enumerate(jobs)]
         failure = None
         try:
-            recs = run_farm(trials, None, dist, run_group=lambda items: run_group(items, jobs), group_key=key_of(jobs))
+            recs = run_farm(trials, None, dist, run_group=lambda items: run_group(items, jobs), group_key=key_of(jobs),
+                            cost=cost_of)
         except FarmError as exc:        # finished trials are kept and written out below, then the error surfaces
             recs, failure = exc.records, exc
         objective = recs[0]["objective"] if len(recs) == 1 else None
     else:
         sw = stamp_cfg.get("hydra", {}).get("sweeper", {}) or {}
         n_trials = int(sw.get("n_trials", 15))
-        # Candidates per round.  The reference asks Optuna for `n_jobs` trials at a time and runs them as
-        # `n_jobs` processes on one machine.  Here ONE GPU advances a whole batch of equal-N trials with the same
-        # launches at little more than the cost of one (an N=128 trial fills 64 of the 256 CUs), so every rank
-        # gets `trials_per_gpu` candidates per round (default: the experiment's n_jobs) and a round asks for
-        # trials_per_gpu x world of them.  With world = 1 this IS the reference's n_jobs; with more GPUs the
-        # sampler sees results in larger rounds, i.e. the TPE sequence depends on the world size (the reference's
-        # sampler seed is unset anyway: its sequence is not reproducible from run to run either).
+        # Candidates per round (utilities.sweep.farm.plan_rounds): a sampler learns only between rounds, so the round
+        # size is part of the search.  mode "reference": rounds of the experiment's n_jobs whatever the world size (the
+        # reference's ask n_jobs / run / tell n_jobs); mode "throughput" (default): every GPU is offered
+        # `trials_per_gpu` candidates (default n_jobs) per round -- ONE GPU advances a batch of equal-N trials with the
+        # same launches at little more than the cost of one -- but a study never has fewer than three rounds, so
+        # that model-guided rounds remain (one round of n_trials candidates is a random search).  With one GPU both
+        # modes give the reference's sequence.  The sampler's seed is fixed (the reference's is unset).
         per_gpu = int(os.environ.get("LDC_TRIALS_PER_GPU", sw.get("trials_per_gpu", sw.get("n_jobs", 1))))
-        n_jobs = max(1, per_gpu) * dist.world
+        mode = str(os.environ.get("LDC_SEARCH_MODE", sw.get("search_mode", "throughput"))).lower()
+        rounds = plan_rounds(n_trials, int(sw.get("n_jobs", 1)), dist.world, per_gpu=per_gpu, mode=mode,
+                             min_rounds=int(os.environ.get("LDC_MIN_ROUNDS", sw.get("min_rounds", 3))))
+        if len(rounds) < 3:
+            log.warning("this study runs in %d round(s) of %s candidates: the sampler is told results only between "
+                        "rounds, so fewer than 3 rounds is (nearly) a random search", len(rounds), rounds)
+        log.info("search: %d trials in %d rounds %s (mode %s, %d GPU(s), %d candidates per GPU and round at most)",
+                 n_trials, len(rounds), rounds, mode, dist.world, per_gpu)
         seed = int((sw.get("sampler") or {}).get("seed", 0))
         sampler = TPESampler(space, seed=seed)
         recs, done, failure = [], 0, None
-        while done < n_trials:
-            batch = [sampler.ask() for _ in range(min(n_jobs, n_trials - done))]
+        for rnd, size in enumerate(rounds):
+            guided = sampler.is_guided()                  # does this round come from the model or from the prior?
+            batch = [sampler.ask() for _ in range(size)]
             jobs = [list(b.items()) for b in batch]
             open_parents(jobs, done)
             trials = [dict(b, N=b.get("N", base_cfg.get("N", 32)), _job=i) for i, b in enumerate(batch)]
             # a failed trial is a failed trial (objective inf), like an exception inside an Optuna objective
             out = run_farm(trials, None, dist, run_group=lambda items: run_group(items, jobs, done),
-                           group_key=key_of(jobs), raise_on_error=False)
+                           group_key=key_of(jobs), raise_on_error=False, cost=cost_of)
             for b, r in zip(batch, out):
                 sampler.tell(b, r["objective"] if isinstance(r["objective"], (int, float)) else math.inf)
+                r.update(search_round=rnd, search_round_size=size, search_rounds=len(rounds), search_mode=mode,
+                         search_model_guided=bool(guided))
             recs.extend(out)
             done += len(batch)
         best, val = sampler.best

@@ -286,12 +286,22 @@ class SGSolver(LidDrivenCavitySolver):
         import torch
         with torch.cuda.device(self.device):      # the handle belongs to the device that is current here
             L.check(L.lib().ldc_solver_create(C.byref(pr), C.byref(h)), "ldc_solver_create")
-        L.check(L.lib().ldc_solver_set_graph_iters(h, int(self.params.graph_iters)), "ldc_solver_set_graph_iters")
-        mode = int(self.params.persistent)
-        if mode == 2 and self.T * self.T > L.PERSIST_XCD_TILES:
-            mode = 0          # one-XCD placement where a trial fits one XCD (the coarse levels of a hierarchy), launches elsewhere
-        L.check(L.lib().ldc_solver_set_persistent(h, mode), "ldc_solver_set_persistent")
+        # owned from here on: a setter that fails below must not leak the handle (close() destroys it)
         self._handle, self._handle_tol = h, tol
+        try:
+            L.check(L.lib().ldc_solver_set_graph_iters(h, int(self.params.graph_iters)), "ldc_solver_set_graph_iters")
+            mode = int(self.params.persistent)
+            # A persistent mode on a size it cannot run (mode 2: more tiles than one XCD holds; mode 1: more tiles than
+            # the device has CUs, e.g. the fine level of a hierarchy) falls back to the launch path -- both the same way:
+            # a configuration asks for "persistent where it applies", the levels of one FSG solve differ in size.
+            n_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+            if (mode == 2 and self.T * self.T > L.PERSIST_XCD_TILES) or (mode == 1 and self.T * self.T > n_cus):
+                mode = 0
+            L.check(L.lib().ldc_solver_set_persistent(h, mode), "ldc_solver_set_persistent")
+        except Exception:
+            self.close()
+            self._handle_key = None
+            raise
 
     def _sync(self):
         """Wait for this solver's work: everything it enqueues goes to the calling thread's current stream of its

@@ -19,10 +19,101 @@ import numpy as np
 log = logging.getLogger(__name__)
 
 
-def trial_cost(trial: dict) -> float:
-    """Relative cost model for scheduling: N^3 per step times ~N^2 steps to converge."""
-    n = float(dict(trial).get("N", 32))
-    return n**5
+# Measured on one MI355X (profiles/r02_sweeps_streams.md, BASELINE config 4 at full size, reference stopping rule):
+# iterations to the reference's convergence criterion and microseconds per full iteration of a lone trial.
+_SG_ITERATIONS = {(64, 100): 306441, (64, 400): 273012, (64, 1000): 247661,
+                  (128, 100): 656077, (128, 400): 895532, (128, 1000): 832853,
+                  (256, 100): 1050762, (256, 400): 1088448, (256, 1000): 1299041}
+_US_PER_ITERATION = {16: 26.0, 32: 26.5, 64: 31.8, 128: 38.3, 256: 52.8}      # SG, launch path, with E/Z/P
+_FSG_COARSE_ITERATIONS = 250_000      # config 5 (N=128, Re=1000): the 64-level takes ~250 k iterations, the 128-level ~35 k
+_FSG_FINE_ITERATIONS = 35_000
+_SMOOTHER_LAUNCH_FACTOR = 8.0 / 5.0   # smoother mode: eight launches per iteration instead of five
+
+
+def _interp_log(table: dict, x: float) -> float:
+    """Piecewise log-log interpolation of a {size: value} table, power-law extrapolation beyond its ends."""
+    keys = sorted(table)
+    if x <= keys[0]:
+        lo, hi = keys[0], keys[1]
+    elif x >= keys[-1]:
+        lo, hi = keys[-2], keys[-1]
+    else:
+        hi = next(k for k in keys if k >= x)
+        lo = keys[keys.index(hi) - 1] if hi != x else hi
+        if lo == hi:
+            return float(table[hi])
+    slope = math.log(table[hi] / table[lo]) / math.log(hi / lo)
+    return float(table[lo] * (x / lo) ** slope)
+
+
+def us_per_iteration(n: float) -> float:
+    """Microseconds per iteration of one SG trial of order n (beyond N=256 a stage is MFMA-bound: ~N^3)."""
+    if n > 256:
+        return _US_PER_ITERATION[256] * (n / 256.0) ** 3
+    return _interp_log(_US_PER_ITERATION, max(n, 16.0))
+
+
+def expected_iterations(n: float, re: float) -> float:
+    """Iterations to the reference's stopping rule: the measured table at the nearest Re, log-log in N."""
+    res = sorted({r for _, r in _SG_ITERATIONS})
+    r = min(res, key=lambda q: abs(math.log(q / max(re, 1e-9))))
+    return _interp_log({k: v for (k, rr), v in _SG_ITERATIONS.items() if rr == r}, max(n, 8.0))
+
+
+def trial_cost(trial: dict, solver: str = None) -> float:
+    """Expected GPU seconds of a trial, for longest-first scheduling: measured iteration counts (N, Re) times the
+    measured time per iteration (N), by solver class -- an FSG trial is its coarse level plus a short fine level
+    in smoother mode.  (Round 2 used N^5, which ignores Re and the solver class: the N=256, Re=1000 trial of config 4
+    is 1.3 M iterations, the N=256, Re=100 one 1.05 M.)  ``solver``: class hint ("fsg" in it selects the FSG model);
+    a trial's own "solver" entry wins."""
+    t = dict(trial)
+    n, re = float(t.get("N", 32)), float(t.get("Re", 100))
+    kind = str(t.get("solver", solver or "")).lower()
+    if "fsg" in kind:
+        levels = int(t.get("n_levels", t.get("solver.n_levels", 2)))
+        cost, m = 0.0, n
+        for lvl in range(levels):
+            its = _FSG_FINE_ITERATIONS if lvl == 0 and levels > 1 else _FSG_COARSE_ITERATIONS
+            cost += its * us_per_iteration(m) * _SMOOTHER_LAUNCH_FACTOR
+            if m // 2 < 12:
+                break
+            m //= 2
+        return cost * 1e-6
+    return expected_iterations(n, re) * us_per_iteration(n) * 1e-6
+
+
+def plan_rounds(n_trials: int, n_jobs: int, world: int, per_gpu: int = None, mode: str = "throughput",
+                min_rounds: int = 3) -> list:
+    """Sizes of the ask/tell rounds of a model-based search (sum = n_trials).
+
+    The reference asks Optuna for ``n_jobs`` candidates, runs them as ``n_jobs`` processes and tells the results
+    (conf/experiment/optimization/corner_smoothing.yaml:50-57; scripts/hpc_submit.py:103-107 for grids).  A sampler
+    only learns BETWEEN rounds, so the round size is a property of the search, not only of the machine:
+
+    * ``mode="reference"``: every round is ``n_jobs`` candidates whatever the world size -- the reference's own
+      sequence of asks and tells.  More GPUs then only spread a round (n_jobs = 8 on 8 GPUs: one trial per GPU);
+      since one MI355X advances eight equal-N trials as a batch in about the time of one, the wall time of a round
+      barely changes: no throughput scaling beyond batching.
+    * ``mode="throughput"`` (default): a round offers every GPU ``per_gpu`` candidates (default ``n_jobs``), i.e. up to
+      ``per_gpu x world`` -- but never so many that the study has fewer than ``min_rounds`` rounds (default 3): with
+      ONE round of n_trials candidates the sampler would never see a result and the study would be a random search
+      (round 2's behaviour at world >= n_trials / n_jobs).  The trials are split evenly over
+      max(min_rounds, ceil(n_trials / capacity)) rounds.  With one GPU this is the reference's sequence whenever
+      that has at least ``min_rounds`` rounds; with more GPUs the speed-up of a search is bounded by
+      rounds(1 GPU) / rounds(N GPUs) -- config 5 (64 trials, n_jobs 8): 8 rounds -> 3, at most 2.7x at any GPU count.
+    """
+    n_trials, n_jobs, world = int(n_trials), max(1, int(n_jobs)), max(1, int(world))
+    if n_trials <= 0:
+        return []
+    if mode == "reference":
+        size = n_jobs
+        return [min(size, n_trials - lo) for lo in range(0, n_trials, size)]
+    if mode != "throughput":
+        raise ValueError(f"unknown search mode {mode!r}: use 'reference' or 'throughput'")
+    capacity = max(1, int(per_gpu if per_gpu is not None else n_jobs)) * world
+    n_rounds = min(n_trials, max(int(min_rounds), -(-n_trials // capacity)))
+    base, extra = divmod(n_trials, n_rounds)
+    return [base + (1 if k < extra else 0) for k in range(n_rounds)]
 
 
 def assign_lpt(costs, n_workers: int) -> list:
@@ -177,6 +268,11 @@ class TPESampler:
                 cnt = sum(1 for v in vals if v == x[k])
                 s += math.log((cnt + 1.0) / (len(vals) + len(dom)))
         return s
+
+    def is_guided(self) -> bool:
+        """True once ``ask`` draws from the model (enough finite results have been told), False while it samples
+        the prior."""
+        return sum(1 for v in self.values if math.isfinite(v)) >= self.n_startup
 
     def ask(self) -> dict:
         finite = [(t, v) for t, v in zip(self.trials, self.values) if math.isfinite(v)]

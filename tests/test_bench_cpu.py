@@ -33,6 +33,19 @@ def test_flop_count_is_the_necessary_one():
     assert b.flops_per_step(256, True) - b.flops_per_step(256, False) == 8.0 * M**3
 
 
+def test_ghia_block_carries_the_metrics_second_half():
+    """BASELINE's metric is "time-steps/s ...; Ghia centreline L2 error": the bench line carries both figures of the
+    bench config (reference stopping rule; converged to 1e-9) from the committed reports, labelled as such."""
+    b = _bench()
+    g = b.ghia_block(256, 1000.0)
+    assert "not a live measurement" in g["kind"]
+    ref, tight = g["reference_stopping_rule_tol_1e-6"], g["converged_tol_1e-9"]
+    assert ref["iterations"] == 1299041 and abs(ref["u_rms"] - 0.2197) < 1e-3 and abs(ref["v_rms"] - 0.2901) < 1e-3
+    assert tight["iterations"] == 64603605 and abs(tight["u_rms"] - 0.0103) < 1e-4 and abs(tight["v_rms"] - 0.0071) < 1e-4
+    assert (ROOT / ref["source"]).exists() and (ROOT / tight["source"]).exists()
+    assert b.ghia_block(48, 1000.0) is None                      # no committed solve for that size
+
+
 def test_committed_bench_line_keeps_the_contract():
     files = sorted((ROOT / "profiles").glob("r*_bench.json"))
     assert files, "no committed bench line"

@@ -143,3 +143,79 @@ def test_tpe_sampler_finds_a_1d_minimum():
     assert abs(best["x"] - 0.27) < 0.05 and val < 2.5e-3
     s.tell({"x": 0.5}, float("nan"))            # failed trials are tolerated
     assert s.ask() is not None
+
+
+# ------------------------------------------------------------------------------ search rounds / scheduling
+def test_search_rounds_keep_the_model_in_the_loop():
+    """A sampler learns only between rounds.  Round size = trials_per_gpu x world (round 2) made the shipped study
+    (n_trials 15, n_jobs 5, TPE start-up 8) ONE round on three or more GPUs -- a random search.  plan_rounds never
+    plans fewer than three rounds, and the reference's own sequence is available as a mode."""
+    from utilities.sweep.farm import plan_rounds
+    # the shipped sweeper config (conf/experiment/optimization/corner_smoothing.yaml:26-27)
+    assert plan_rounds(15, 5, 1) == [5, 5, 5] == plan_rounds(15, 5, 8) == plan_rounds(15, 5, 8, mode="reference")
+    # BASELINE config 5: 64 trials, n_jobs 8
+    assert plan_rounds(64, 8, 1) == [8] * 8 == plan_rounds(64, 8, 8, mode="reference")      # the reference's asks / tells
+    assert plan_rounds(64, 8, 8) == [22, 21, 21]                  # throughput mode: as few rounds as allowed, never < 3
+    assert plan_rounds(64, 8, 2) == [16] * 4 and plan_rounds(64, 8, 4) == [22, 21, 21]
+    assert plan_rounds(64, 8, 8, per_gpu=1) == [8] * 8            # trials_per_gpu = 1: one trial per GPU and round
+    assert plan_rounds(2, 8, 8) == [1, 1] and plan_rounds(0, 8, 8) == []
+    assert sum(plan_rounds(37, 5, 3)) == 37
+    with pytest.raises(ValueError):
+        plan_rounds(10, 2, 1, mode="fastest")
+    # at world = 8 with the shipped config some trial must come from the TPE branch
+    s = TPESampler({"x": C.Interval(0.01, 0.10)}, seed=0)          # n_startup = 8
+    guided = []
+    for size in plan_rounds(15, 5, 8):
+        guided.append(s.is_guided())
+        batch = [s.ask() for _ in range(size)]
+        for b in batch:
+            s.tell(b, (b["x"] - 0.03) ** 2)
+    assert guided == [False, False, True]                          # 10 results told before the third round
+    s = TPESampler({"x": C.Interval(0.01, 0.10)}, seed=0)
+    guided = []
+    for size in plan_rounds(64, 8, 8):
+        guided.append(s.is_guided())
+        for b in [s.ask() for _ in range(size)]:
+            s.tell(b, (b["x"] - 0.03) ** 2)
+    assert guided == [False, True, True]
+
+
+def test_trial_cost_follows_the_measured_iteration_counts():
+    """Scheduling weight = measured iterations (N, Re) x measured time per iteration (N), by solver class
+    (profiles/r02_sweeps_streams.md); N^5 ignored Re and the solver class."""
+    from utilities.sweep.farm import trial_cost, expected_iterations, us_per_iteration
+    assert expected_iterations(256, 1000) == 1299041 and expected_iterations(64, 400) == 273012
+    assert trial_cost(dict(N=256, Re=1000)) == pytest.approx(1299041 * 52.8e-6)
+    assert trial_cost(dict(N=256, Re=1000)) > trial_cost(dict(N=256, Re=400)) > trial_cost(dict(N=256, Re=100))
+    assert trial_cost(dict(N=128, Re=400)) > trial_cost(dict(N=128, Re=1000))            # 895 k vs 833 k iterations
+    assert us_per_iteration(512) == pytest.approx(52.8 * 8) and 26.0 <= us_per_iteration(48) <= 31.8
+    assert 4.0 < trial_cost(dict(N=48, Re=250)) < trial_cost(dict(N=64, Re=250))        # interpolated, monotone in N
+    fsg = trial_cost(dict(N=128, Re=1000), solver="solvers.spectral.fsg.FSGSolver")
+    assert fsg < trial_cost(dict(N=128, Re=1000)) and fsg == trial_cost(dict(N=128, Re=1000, solver="spectral/fsg"))
+
+
+def test_a_failing_unbatched_trial_costs_only_its_own_record(tmp_path, monkeypatch):
+    """run_group: trials that do not share launches (here two sizes with one member each) run one by one; one of
+    them raising must not wipe the record of the other (utilities.sweep.farm: 'costs only its own trials')."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("ldc_main_under_test", PKG / "main.py")
+    main = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(main)
+
+    def fake_run_solver(cfg, out_dir, device=None):
+        if cfg["N"] == 24:
+            raise RuntimeError("solver blew up")
+        return dict(objective=0.5, N=cfg["N"], Re=cfg["Re"])
+
+    monkeypatch.setattr(main, "run_solver", fake_run_solver)
+    monkeypatch.chdir(tmp_path)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(main.FarmError) as ei:
+        main.main(["-m", "N=16,24,40", "Re=100", f"hydra.sweep.dir={tmp_path}/sweep"])
+    recs = ei.value.records
+    assert [("error" in r) for r in recs] == [False, True, False]
+    assert recs[0]["objective"] == 0.5 and recs[2]["N"] == 40 and "solver blew up" in recs[1]["error"]
+    saved = json.loads((tmp_path / "sweep" / "sweep_results.json").read_text())
+    assert [("error" in r) for r in saved] == [False, True, False]
