@@ -95,11 +95,11 @@ def plan_rounds(n_trials: int, n_jobs: int, world: int, per_gpu: int = None, mod
       since one MI355X advances eight equal-N trials as a batch in about the time of one, the wall time of a round
       barely changes: no throughput scaling beyond batching.
     * ``mode="throughput"`` (default): a round offers every GPU ``per_gpu`` candidates (default ``n_jobs``), i.e. up to
-      ``per_gpu x world`` -- but never so many that the study has fewer than ``min_rounds`` rounds (default 3): with
-      ONE round of n_trials candidates the sampler would never see a result and the study would be a random search
-      (round 2's behaviour at world >= n_trials / n_jobs).  The trials are split evenly over
-      max(min_rounds, ceil(n_trials / capacity)) rounds.  With one GPU this is the reference's sequence whenever
-      that has at least ``min_rounds`` rounds; with more GPUs the speed-up of a search is bounded by
+      ``per_gpu x world`` -- but never so many that the study has fewer than ``min_rounds`` rounds (default 3; fewer
+      only where the reference's own sequence has fewer): with ONE round of n_trials candidates the sampler would
+      never see a result and the study would be a random search (round 2's behaviour at world >= n_trials / n_jobs).
+      The trials are split evenly over max(min(min_rounds, reference rounds), ceil(n_trials / capacity)) rounds.
+      With one GPU (and per_gpu = n_jobs) this IS the reference's sequence; with more GPUs the speed-up of a search is bounded by
       rounds(1 GPU) / rounds(N GPUs) -- config 5 (64 trials, n_jobs 8): 8 rounds -> 3, at most 2.7x at any GPU count.
     """
     n_trials, n_jobs, world = int(n_trials), max(1, int(n_jobs)), max(1, int(world))
@@ -111,7 +111,8 @@ def plan_rounds(n_trials: int, n_jobs: int, world: int, per_gpu: int = None, mod
     if mode != "throughput":
         raise ValueError(f"unknown search mode {mode!r}: use 'reference' or 'throughput'")
     capacity = max(1, int(per_gpu if per_gpu is not None else n_jobs)) * world
-    n_rounds = min(n_trials, max(int(min_rounds), -(-n_trials // capacity)))
+    ref_rounds = -(-n_trials // n_jobs)                       # what the reference's own sequence has
+    n_rounds = min(n_trials, max(min(int(min_rounds), ref_rounds), -(-n_trials // capacity)))
     base, extra = divmod(n_trials, n_rounds)
     return [base + (1 if k < extra else 0) for k in range(n_rounds)]
 

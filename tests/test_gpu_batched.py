@@ -236,3 +236,37 @@ def test_worker_streams_come_in_three_priorities():
     again = []
     batched.run_concurrently([0, 1, 2], lambda k: again.append((k, torch.cuda.current_stream().cuda_stream)))
     assert dict(seen) == dict(again)                        # the same three streams every time
+
+
+def test_batches_built_and_closed_while_another_thread_replays_graphs():
+    """The library's hot calls (hipGraphLaunch on the caller's stream) take no lock, while graph capture, instantiation
+    and destruction of graph executables run under its process-wide mutex on a kept private stream.  Thread A builds,
+    runs briefly and closes batch after batch (captures + instantiations + exec destructions) while thread B keeps
+    replaying the graphs of a batch of its own and waiting on its stream: B's records must equal an undisturbed run
+    bit for bit, nothing may abort (round 2's runtime abort with per-handle capture streams: DESIGN.md 3, streams)."""
+    import threading
+    import torch
+    from solvers.spectral.batched import BatchedSGSolver, run_concurrently
+    trials_b = [kw(32, 100, 0.15, graph_iters=8), kw(32, 400, 0.10, graph_iters=8)]
+    ref = BatchedSGSolver(trials_b)
+    want = ref.run_iterations(1200, diagnostics=False)
+    ref.close()
+    got, built = {}, []
+
+    def job(which):
+        if which == "A":
+            for k in range(6):
+                b = BatchedSGSolver([kw(24, 100 + 50 * k, 0.1, graph_iters=4), kw(24, 200, 0.2, graph_iters=4)])
+                b.run_iterations(16, diagnostics=(k % 2 == 0))       # capture + instantiate (both graph flavours in turn)
+                b.close()                                            # hipGraphExecDestroy under the mutex
+                built.append(k)
+        else:
+            b = BatchedSGSolver(trials_b)
+            rows = [b.run_iterations(100, diagnostics=False) for _ in range(12)]      # replays + stream-level waits
+            got["B"] = [np.concatenate([r[q] for r in rows], axis=0) for q in range(2)]
+            b.close()
+
+    run_concurrently(["A", "B"], job)
+    assert built == list(range(6))
+    for w, g in zip(want, got["B"]):
+        assert np.array_equal(w, g)

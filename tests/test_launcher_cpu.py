@@ -158,7 +158,8 @@ def test_search_rounds_keep_the_model_in_the_loop():
     assert plan_rounds(64, 8, 8) == [22, 21, 21]                  # throughput mode: as few rounds as allowed, never < 3
     assert plan_rounds(64, 8, 2) == [16] * 4 and plan_rounds(64, 8, 4) == [22, 21, 21]
     assert plan_rounds(64, 8, 8, per_gpu=1) == [8] * 8            # trials_per_gpu = 1: one trial per GPU and round
-    assert plan_rounds(2, 8, 8) == [1, 1] and plan_rounds(0, 8, 8) == []
+    assert plan_rounds(2, 8, 8) == [2] and plan_rounds(0, 8, 8) == []       # never MORE rounds than the reference's own
+    assert plan_rounds(8, 4, 1) == [4, 4] == plan_rounds(8, 4, 8)
     assert sum(plan_rounds(37, 5, 3)) == 37
     with pytest.raises(ValueError):
         plan_rounds(10, 2, 1, mode="fastest")
