@@ -2083,6 +2083,11 @@ __global__ __launch_bounds__(kStageThreads, 2) void trial_kernel(const TrialArgs
 }
 
 // ---------------------------------------------------------------------------------------
+// small-N trial kernel: a trial's T x T work-groups on ONE XCD, contraction families per wave, resident operators
+// ---------------------------------------------------------------------------------------
+#include "ldc_xcd_kernel.inc"
+
+// ---------------------------------------------------------------------------------------
 // palinstrophy kernel:  P = 1/2 sum W ((Dx w)^2 + (w Dy^T)^2)
 // ---------------------------------------------------------------------------------------
 struct PalinArgs {
@@ -2366,7 +2371,10 @@ struct ldc_batch {
   PalinArgs* d_palin;        // stand-alone (closing) form
   PostArgs* d_post_close;    // stand-alone post with omega blocks
   FinalArgs* d_flush;
-  int post_grid[2], postT_grid, post_close_grid;
+  PostArgs* d_postP;         // stand-alone transforms of P (ungated): what follows a launch of the small-N trial kernel
+  XArgs* d_xargs[2];         // [with_diagnostics] argument blocks of the small-N trial kernel
+  unsigned* d_xsync;         // XG_LEN launch words, then XS_LEN counter words per trial (zeroed before every launch)
+  int post_grid[2], postT_grid, post_close_grid, postP_grid;
   int iters_per_graph;
   hipGraphExec_t graph[2];
   hipStream_t capture_stream;
@@ -2624,15 +2632,85 @@ bool persistent_available(const ldc_solver* s) {
 bool local_available(const ldc_solver* s) {
   return persistent_available(s) && s->nt <= LDC_PERSIST_XCD_TILES && s->nt + 4 <= s->n_cus / s->n_xcds;
 }
-// 0: launch per stage   1: persistent trial kernel   2: persistent, one-XCD placement
+bool xcd_available(const ldc_solver* s);
+int xcd_tiles(const ldc_solver* s);
+// 0: launch per stage   1: persistent trial kernel   2: persistent, one-XCD placement   3: small-N trial kernel
 int persistent_mode(const ldc_solver* s) {
-  if (s->persist_mode == 0 || !persistent_available(s)) return 0;
+  if (s->persist_mode == 0) return 0;
+  if (s->persist_mode == 3) return xcd_available(s) ? 3 : 0;
+  if (s->persist_mode == -1 && xcd_available(s) && xcd_tiles(s) * xcd_tiles(s) <= LDC_XCD_AUTO_TILES) return 3;
+  if (!persistent_available(s)) return 0;
   if (s->persist_mode == 2) return local_available(s) ? 2 : 0;
   if (s->persist_mode == 1) return 1;
   if (local_available(s) && s->nt <= LDC_PERSIST_AUTO_XCD_TILES) return 2;
   return s->nt <= LDC_PERSIST_AUTO_TILES ? 1 : 0;
 }
-bool use_persistent(const ldc_solver* s) { return persistent_mode(s) != 0; }
+bool use_persistent(const ldc_solver* s) { const int m = persistent_mode(s); return m == 1 || m == 2; }
+
+// ---- small-N trial kernel (mode 3) -----------------------------------------------------------------------------
+constexpr size_t kXcdLdsBytes = XLds::BYTES;
+static_assert(kXcdLdsBytes <= 64 * 1024 - 256, "small-N trial kernel LDS (plus its static words) within the default limit");
+int xcd_tiles(const ldc_solver* s) { return (s->p.M + 15) / 16; }
+// every tile's work-group on one XCD, one per CU; the packed arrays hold T x T blocks; a partial-sum row per tile
+bool xcd_available(const ldc_solver* s) {
+  const int T = xcd_tiles(s);
+  return s->p.sync != nullptr && s->ablate == 0 && T <= kXT && T * T <= s->n_cus / s->n_xcds && s->p.LD / 16 >= T &&
+         s->p.partials_stride >= (int64_t)T * T * LDC_NPART;
+}
+bool use_xcd(const ldc_solver* s) { return persistent_mode(s) == 3; }
+
+XArgs make_xargs(const ldc_solver* s, int with_diag, unsigned* sync) {
+  const ldc_problem& p = s->p;
+  XArgs a;
+  memset(&a, 0, sizeof(a));
+  a.M = p.M; a.LD = p.LD; a.NB = p.LD / 16; a.T = xcd_tiles(s);
+  a.with_diag = with_diag;
+  a.nu = p.nu; a.beta2 = p.beta2;
+  a.DxK = p.DxK; a.D2xK = p.D2xK; a.DyK = p.DyK; a.D2yK = p.D2yK;
+  a.IxFK = p.IxFK; a.GxFK = p.GxFK; a.IyFK = p.IyFK; a.GyFK = p.GyFK;
+  a.ulid = p.ulid; a.wx = p.wx; a.wy = p.wy;
+  a.U = p.U; a.UT = p.UT; a.V = p.V; a.VT = p.VT; a.P = p.P;
+  a.UK[0] = p.UK; a.UK[1] = p.UAK; a.UK[2] = p.UBK;
+  a.UTK[0] = p.UTK; a.UTK[1] = p.UATK; a.UTK[2] = p.UBTK;
+  a.VK[0] = p.VK; a.VK[1] = p.VAK; a.VK[2] = p.VBK;
+  a.VTK[0] = p.VTK; a.VTK[1] = p.VATK; a.VTK[2] = p.VBTK;
+  a.PK[0] = p.PK; a.PK[1] = p.PAK; a.PK[2] = p.PBK;
+  a.T1TK = p.T1TK; a.T2TK = p.T2TK; a.WK = p.WK; a.WTK = p.WTK;
+  a.part4 = p.partials; a.partZ0 = p.partials + p.partials_stride; a.partP0 = p.partials + 3 * p.partials_stride;
+  a.stride = p.partials_stride;
+  a.fin = make_final_args(s, with_diag, 1);
+  a.sync = sync;
+  a.giveup = p.sync + LDC_SYNC_GIVEUP;
+  return a;
+}
+
+template <typename K>
+int xcd_launch_kernel(K kern, const XLaunch& xl, int nwg, int n_xcds, hipStream_t st) {
+  // work-groups are dealt round-robin over the XCDs: (slots x tiles + 8) per XCD put at least slots x tiles of them on
+  // every XCD; the surplus leaves at once
+  const int per_xcd = ((xl.B + n_xcds - 1) / n_xcds) * nwg + 8;
+  hipLaunchKernelGGL(kern, dim3(n_xcds * per_xcd), dim3(kStageThreads), kXcdLdsBytes, st, xl);
+  return (int)hipGetLastError();
+}
+int xcd_launch_any(const XLaunch& xl, bool sp, bool diag, int nwg, int n_xcds, hipStream_t st) {
+  if (sp) return xcd_launch_kernel(xcd_kernel<true, false>, xl, nwg, n_xcds, st);
+  if (diag) return xcd_launch_kernel(xcd_kernel<false, true>, xl, nwg, n_xcds, st);
+  return xcd_launch_kernel(xcd_kernel<false, false>, xl, nwg, n_xcds, st);
+}
+
+// one trial: counters in words [0, XS_LEN) and the launch words in [LDC_SYNC_XLAUNCH, +XG_LEN) of its own sync array
+int launch_xcd(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
+  const int T = xcd_tiles(s);
+  XLaunch xl;
+  memset(&xl, 0, sizeof(xl));
+  xl.B = 1; xl.n_iters = n_iters; xl.slots_per_xcd = 1;
+  xl.gsync = s->p.sync + LDC_SYNC_XLAUNCH;
+  xl.trials = nullptr;
+  xl.one = make_xargs(s, with_diag, s->p.sync);
+  HIP_TRY(hipMemsetAsync(s->p.sync, 0, sizeof(uint32_t) * LDC_SYNC_GIVEUP, st));
+  HIP_TRY(hipMemsetAsync(s->p.sync + LDC_SYNC_XLAUNCH, 0, sizeof(uint32_t) * XG_LEN, st));
+  return xcd_launch_any(xl, s->p.stage_pressure != 0, with_diag != 0, T * T, s->n_xcds, st);
+}
 
 TrialArgs make_trial_args(const ldc_solver* s, int n_iters, int with_diag) {
   TrialArgs ta;
@@ -2726,8 +2804,8 @@ int build_graph(ldc_solver* s, int with_diag) {
 
 size_t batch_bytes(int B) {
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
-  return 4 * up(sizeof(StageArgs) * B) + 5 * up(sizeof(PostArgs) * B) + up(sizeof(PalinArgs) * B) +
-         up(sizeof(FinalArgs) * B);
+  return 4 * up(sizeof(StageArgs) * B) + 6 * up(sizeof(PostArgs) * B) + up(sizeof(PalinArgs) * B) +
+         up(sizeof(FinalArgs) * B) + 2 * up(sizeof(XArgs) * B) + up(sizeof(uint32_t) * (XG_LEN + (size_t)XS_LEN * B));
 }
 
 int batch_launch_stage(ldc_batch* b, int k, int diag, hipStream_t st) {
@@ -2889,10 +2967,11 @@ int ldc_solver_set_graph_iters(ldc_solver* s, int n) {
 
 int ldc_solver_set_persistent(ldc_solver* s, int mode) {
   if (!s) return LDC_E_STATE;
-  if (mode < -1 || mode > 2) return LDC_E_ARG;
-  if (mode >= 1 && (s->p.sync == nullptr || s->nt > s->n_cus)) return LDC_E_ARG;
+  if (mode < -1 || mode > 3) return LDC_E_ARG;
+  if ((mode == 1 || mode == 2) && (s->p.sync == nullptr || s->nt > s->n_cus)) return LDC_E_ARG;
   s->persist_mode = mode;
   if (mode == 2 && !local_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }
+  if (mode == 3 && !xcd_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }
   return 0;
 }
 
@@ -2999,6 +3078,14 @@ int ldc_solver_enqueue(ldc_solver* s, int n_iters, int with_diag, void* stream) 
   // (a single iteration always goes launch by launch: nothing to gain, and it is the form the host uses for the first
   //  iteration after an upload, when phi^n may still carry other values on the row / column of index M-1 than the
   //  stage buffers do -- the tile-resident kernel stages those boundary values ONCE, from phi^n)
+  if (n_iters > 1 && use_xcd(s)) {
+    // the small-N trial kernel, then the transforms of the final pressure in the launch path's form (row M-1 of the
+    // row-major T1T / T2T in the tail layout): whatever runs next finds the state it expects
+    int e = launch_xcd(s, n_iters, with_diag, st);
+    if (e) return e;
+    if ((e = launch_post(s, s->p.P, 0, 0, 0, st)) != 0) return e;
+    return with_diag ? launch_closing_diagnostics(s, st) : 0;
+  }
   if (n_iters > 1 && use_persistent(s)) {
     const int e = launch_trial(s, n_iters, with_diag, st);
     if (e) return e;
@@ -3089,6 +3176,25 @@ int ldc_batch_create(ldc_solver* const* solvers, int n_trials, void* workspace, 
     b->d_flush = reinterpret_cast<FinalArgs*>(carve(sizeof(FinalArgs) * n_trials));
     put(b->d_flush, f.data(), sizeof(FinalArgs) * n_trials);
   }
+  {
+    std::vector<PostArgs> hp(n_trials);
+    for (int q = 0; q < n_trials; ++q) {
+      hp[q] = make_post_args(solvers[q], solvers[q]->p.P, 0, 0, 0, &b->postP_grid);
+      hp[q].wt = write_through_policy(solvers[q], solvers[q]->nt * n_trials);
+    }
+    b->d_postP = reinterpret_cast<PostArgs*>(carve(sizeof(PostArgs) * n_trials));
+    put(b->d_postP, hp.data(), sizeof(PostArgs) * n_trials);
+    // the counter words first (their addresses go into the argument blocks), then the blocks themselves
+    char* xa0 = carve(sizeof(XArgs) * n_trials);
+    char* xa1 = carve(sizeof(XArgs) * n_trials);
+    b->d_xsync = reinterpret_cast<unsigned*>(carve(sizeof(uint32_t) * (XG_LEN + (size_t)XS_LEN * n_trials)));
+    for (int wd = 0; wd < 2; ++wd) {
+      std::vector<XArgs> hx(n_trials);
+      for (int q = 0; q < n_trials; ++q) hx[q] = make_xargs(solvers[q], wd, b->d_xsync + XG_LEN + (size_t)XS_LEN * q);
+      b->d_xargs[wd] = reinterpret_cast<XArgs*>(wd == 0 ? xa0 : xa1);
+      put(b->d_xargs[wd], hx.data(), sizeof(XArgs) * n_trials);
+    }
+  }
   if (he != hipSuccess) { delete b; return (int)he; }
   *out = b;
   return 0;
@@ -3110,6 +3216,36 @@ int ldc_batch_enqueue(ldc_batch* b, int n_iters, int with_diag, void* stream) {
   { const int e = on_own_device(b->s[0]); if (e) return e; }
   with_diag = with_diag ? 1 : 0;
   hipStream_t st = as_stream(stream);
+  {
+    // small-N trial kernel: every trial of the batch on an XCD of its own (as many trials per launch as the XCDs hold,
+    // the rest in further launches), then the transforms of the final pressures in the launch path's form
+    bool all_xcd = n_iters > 1;
+    for (const ldc_solver* t : b->s) all_xcd = all_xcd && use_xcd(t);
+    if (all_xcd) {
+      const ldc_solver* s0 = b->s[0];
+      const int T = xcd_tiles(s0), nwg = T * T;
+      const int slots = (s0->n_cus / s0->n_xcds) / nwg, per_launch = slots * s0->n_xcds;
+      HIP_TRY(hipMemsetAsync(b->d_xsync + XG_LEN, 0, sizeof(uint32_t) * (size_t)XS_LEN * b->B, st));
+      for (int lo = 0; lo < b->B; lo += per_launch) {
+        XLaunch xl;
+        memset(&xl, 0, sizeof(xl));
+        xl.B = (b->B - lo < per_launch) ? (b->B - lo) : per_launch;
+        // slots in use on every XCD in THIS launch: exactly what the trials need, so that the over-subscription (8 more
+        // work-groups per XCD than needed) can never open a slot that would not fill up
+        xl.n_iters = n_iters; xl.slots_per_xcd = (xl.B + s0->n_xcds - 1) / s0->n_xcds;
+        xl.gsync = b->d_xsync;
+        xl.trials = b->d_xargs[with_diag] + lo;
+        HIP_TRY(hipMemsetAsync(b->d_xsync, 0, sizeof(uint32_t) * XG_LEN, st));
+        const int e = xcd_launch_any(xl, s0->p.stage_pressure != 0, with_diag != 0, nwg, s0->n_xcds, st);
+        if (e) return e;
+      }
+      const PostArgs pdummy = {};
+      hipLaunchKernelGGL(post_kernel<true>, dim3(b->postP_grid, b->B), dim3(kThreads), 0, st, pdummy,
+                         (const PostArgs*)b->d_postP);
+      { const int e = (int)hipGetLastError(); if (e) return e; }
+      return with_diag ? batch_closing_diagnostics(b, st) : 0;
+    }
+  }
   int left = n_iters;
   if (left >= b->iters_per_graph) {
     if (!b->graph[with_diag]) { int e = batch_build_graph(b, with_diag); if (e) return e; }

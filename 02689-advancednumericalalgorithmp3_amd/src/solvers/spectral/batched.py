@@ -141,6 +141,9 @@ class BatchedSGSolver:
             end, done = int(ctrl[L.CTRL_ITER]), int(ctrl[L.CTRL_DONE])
             ring = s.d["rec"].cpu().numpy()
             out.append((ring[np.arange(start, end) % s.rec_cap], done, end))
+            if int(s.d["sync"][L.SYNC_GIVEUP]) != 0:
+                raise L.LdcError("a persistent launch gave up a barrier wait (a work-group was not resident); the "
+                                 "state of the batch is undefined -- rerun with persistent=0")
             if s._edge_fix_pending and end > start:
                 s._write_boundary_edges(("U", "UT", "V", "VT"))
                 s._edge_fix_pending = False

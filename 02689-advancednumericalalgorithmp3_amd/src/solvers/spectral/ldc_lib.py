@@ -16,11 +16,13 @@ LIB_PATH = Path(os.environ.get("LDC_HIP_LIB", _PKG / "lib" / "libldc_hip.so"))
 TIMING_LIB_PATH = _PKG / "lib" / "libldc_hip_timing.so"
 
 REC_LEN, CTRL_LEN, SCAL_LEN, NPART = 8, 8, 8, 12
-SYNC_LEN, SYNC_GIVEUP = 128, 96
+SYNC_LEN, SYNC_GIVEUP = 2048, 96
 ABI_VERSION = 6
 PERSIST_AUTO_TILES = 0      # LDC_PERSIST_AUTO_TILES of include/ldc_hip.h (auto mode picks the persistent kernel up to here)
 PERSIST_XCD_TILES = 25      # LDC_PERSIST_XCD_TILES: mode 2 (all work-groups of a trial on one XCD) is available up to here
 PERSIST_AUTO_XCD_TILES = 0  # LDC_PERSIST_AUTO_XCD_TILES: auto mode picks mode 2 up to here
+XCD_TILES = 25              # LDC_XCD_TILES: mode 3 (the small-N trial kernel) runs trials of up to ceil(M/16)^2 = 25 tiles
+XCD_AUTO_TILES = 0          # LDC_XCD_AUTO_TILES: auto mode picks mode 3 up to here
 REC_REL, REC_RU, REC_RV, REC_RP, REC_E, REC_Z, REC_P, REC_DT = range(8)
 CTRL_DONE, CTRL_ITER = 0, 1
 SCAL_DT, SCAL_UMAX, SCAL_VMAX = 0, 1, 2

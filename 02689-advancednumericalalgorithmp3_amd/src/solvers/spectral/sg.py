@@ -297,6 +297,8 @@ class SGSolver(LidDrivenCavitySolver):
             n_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
             if (mode == 2 and self.T * self.T > L.PERSIST_XCD_TILES) or (mode == 1 and self.T * self.T > n_cus):
                 mode = 0
+            if mode == 3 and ((self.M + 15) // 16) ** 2 > L.XCD_TILES:      # the small-N trial kernel: M <= 80
+                mode = 0
             L.check(L.lib().ldc_solver_set_persistent(h, mode), "ldc_solver_set_persistent")
         except Exception:
             self.close()

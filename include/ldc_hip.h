@@ -94,7 +94,9 @@ enum {
   LDC_SYNC_XCC    = 32,  /* one-XCD placement: 1 + HW XCC id the first arriving work-group elected */
   LDC_SYNC_HEAD   = 64,  /* one-XCD placement: next tile to be claimed by a work-group of that XCD */
   LDC_SYNC_GIVEUP = 96,  /* set to 1 by a work-group whose bounded wait on the counter ran out    */
-  LDC_SYNC_LEN    = 128
+  LDC_SYNC_XLAUNCH = 128, /* small-N trial kernel (mode 3): the launch words of a single-trial launch (tickets per XCD,
+                             the trial each XCD slot took); its two barrier counters use words 0 and 32 */
+  LDC_SYNC_LEN    = 2048
 };
 
 typedef struct ldc_problem {
@@ -200,9 +202,19 @@ int ldc_solver_set_graph_iters(ldc_solver *s, int iters_per_graph);
 /* values of index M-1 (tail layout) once, from U / UT / V / VT: they must equal those of the stage buffers       */
 /* UA.. / UB.. (they do after the first iteration that follows an upload; a call with n_iters == 1 always runs    */
 /* launch by launch).                                                                                             */
+/* mode 3: the small-N trial kernel (csrc/ldc_xcd_kernel.inc) -- ALL n_iters iterations in one launch, the trial's     */
+/* ceil(M/16)^2 work-groups on ONE XCD elected at run time, one contraction family per wave over the full contraction   */
+/* index, the operator fragments resident in registers, state exchanged through that XCD's L2, the pressure path and    */
+/* the fold of the partial sums on waves of their own.  Needs desc->sync and ceil(M/16)^2 <= LDC_XCD_TILES (M <= 80),    */
+/* else LDC_E_ARG.  Reads phi^n from the row-major arrays and leaves row-major and packed forms behind, so it can be     */
+/* mixed with the launch path; trajectories agree with the launch path to rounding, not bit for bit (one accumulation   */
+/* chain per contraction instead of four K-quarters).  In mode -1 it is chosen when ceil(M/16)^2 <= LDC_XCD_AUTO_TILES.  */
+/* A batch (ldc_batch_enqueue) whose trials all resolve to mode 3 runs every trial on an XCD of its own in one launch.   */
 #define LDC_PERSIST_AUTO_TILES 0
 #define LDC_PERSIST_XCD_TILES 25        /* one work-group per CU, 32 CUs per XCD, room left for the over-subscription to drain */
 #define LDC_PERSIST_AUTO_XCD_TILES 0
+#define LDC_XCD_TILES 25
+#define LDC_XCD_AUTO_TILES 0
 int ldc_solver_set_persistent(ldc_solver *s, int mode);
 /* 0, or LDC_E_SYNC when a persistent launch of this handle gave up a barrier wait (a work-group was not         */
 /* resident): the state is then undefined.  Reads desc->sync on the host: SYNCHRONISES the device.               */
