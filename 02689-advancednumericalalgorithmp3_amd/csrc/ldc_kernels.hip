@@ -2649,12 +2649,28 @@ bool use_persistent(const ldc_solver* s) { const int m = persistent_mode(s); ret
 
 // ---- small-N trial kernel (mode 3) -----------------------------------------------------------------------------
 constexpr size_t kXcdLdsBytes = XLds::BYTES;
-static_assert(kXcdLdsBytes <= 64 * 1024 - 256, "small-N trial kernel LDS (plus its static words) within the default limit");
+static_assert(kXcdLdsBytes <= kLdsLimit - 1024, "small-N trial kernel LDS (plus its static words)");
+template <int T>
+int enable_xcd_lds_t() {
+  const void* k[3] = {reinterpret_cast<const void*>(xcd_kernel<T, false, false>), reinterpret_cast<const void*>(xcd_kernel<T, false, true>),
+                      reinterpret_cast<const void*>(xcd_kernel<T, true, false>)};
+  for (const void* f : k) {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXcdLdsBytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+int enable_xcd_lds() {
+  int e;
+  if ((e = enable_xcd_lds_t<1>()) != 0 || (e = enable_xcd_lds_t<2>()) != 0 || (e = enable_xcd_lds_t<3>()) != 0 ||
+      (e = enable_xcd_lds_t<4>()) != 0 || (e = enable_xcd_lds_t<5>()) != 0) return e;
+  return 0;
+}
 int xcd_tiles(const ldc_solver* s) { return (s->p.M + 15) / 16; }
 // every tile's work-group on one XCD, one per CU; the packed arrays hold T x T blocks; a partial-sum row per tile
 bool xcd_available(const ldc_solver* s) {
   const int T = xcd_tiles(s);
-  return s->p.sync != nullptr && s->ablate == 0 && T <= kXT && T * T <= s->n_cus / s->n_xcds && s->p.LD / 16 >= T &&
+  return s->p.sync != nullptr && T <= kXT && T * T <= s->n_cus / s->n_xcds && s->p.LD / 16 >= T &&
          s->p.partials_stride >= (int64_t)T * T * LDC_NPART;
 }
 bool use_xcd(const ldc_solver* s) { return persistent_mode(s) == 3; }
@@ -2681,6 +2697,7 @@ XArgs make_xargs(const ldc_solver* s, int with_diag, unsigned* sync) {
   a.fin = make_final_args(s, with_diag, 1);
   a.sync = sync;
   a.giveup = p.sync + LDC_SYNC_GIVEUP;
+  a.stamps = s->stamps;
   return a;
 }
 
@@ -2692,10 +2709,21 @@ int xcd_launch_kernel(K kern, const XLaunch& xl, int nwg, int n_xcds, hipStream_
   hipLaunchKernelGGL(kern, dim3(n_xcds * per_xcd), dim3(kStageThreads), kXcdLdsBytes, st, xl);
   return (int)hipGetLastError();
 }
-int xcd_launch_any(const XLaunch& xl, bool sp, bool diag, int nwg, int n_xcds, hipStream_t st) {
-  if (sp) return xcd_launch_kernel(xcd_kernel<true, false>, xl, nwg, n_xcds, st);
-  if (diag) return xcd_launch_kernel(xcd_kernel<false, true>, xl, nwg, n_xcds, st);
-  return xcd_launch_kernel(xcd_kernel<false, false>, xl, nwg, n_xcds, st);
+template <int T>
+int xcd_launch_t(const XLaunch& xl, bool sp, bool diag, int n_xcds, hipStream_t st) {
+  if (sp) return xcd_launch_kernel(xcd_kernel<T, true, false>, xl, T * T, n_xcds, st);
+  if (diag) return xcd_launch_kernel(xcd_kernel<T, false, true>, xl, T * T, n_xcds, st);
+  return xcd_launch_kernel(xcd_kernel<T, false, false>, xl, T * T, n_xcds, st);
+}
+int xcd_launch_any(const XLaunch& xl, bool sp, bool diag, int T, int n_xcds, hipStream_t st) {
+  switch (T) {
+    case 1: return xcd_launch_t<1>(xl, sp, diag, n_xcds, st);
+    case 2: return xcd_launch_t<2>(xl, sp, diag, n_xcds, st);
+    case 3: return xcd_launch_t<3>(xl, sp, diag, n_xcds, st);
+    case 4: return xcd_launch_t<4>(xl, sp, diag, n_xcds, st);
+    case 5: return xcd_launch_t<5>(xl, sp, diag, n_xcds, st);
+    default: return LDC_E_ARG;
+  }
 }
 
 // one trial: counters in words [0, XS_LEN) and the launch words in [LDC_SYNC_XLAUNCH, +XG_LEN) of its own sync array
@@ -2709,7 +2737,7 @@ int launch_xcd(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
   xl.one = make_xargs(s, with_diag, s->p.sync);
   HIP_TRY(hipMemsetAsync(s->p.sync, 0, sizeof(uint32_t) * LDC_SYNC_GIVEUP, st));
   HIP_TRY(hipMemsetAsync(s->p.sync + LDC_SYNC_XLAUNCH, 0, sizeof(uint32_t) * XG_LEN, st));
-  return xcd_launch_any(xl, s->p.stage_pressure != 0, with_diag != 0, T * T, s->n_xcds, st);
+  return xcd_launch_any(xl, s->p.stage_pressure != 0, with_diag != 0, T, s->n_xcds, st);
 }
 
 TrialArgs make_trial_args(const ldc_solver* s, int n_iters, int with_diag) {
@@ -2925,8 +2953,9 @@ int ldc_solver_create(const ldc_problem* d, ldc_solver** out) {
   HIP_TRY(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev));
   if (d->sync != nullptr) {
     if ((reinterpret_cast<uintptr_t>(d->sync) & 255) != 0) return LDC_E_ARG;
-    const int e = enable_trial_lds();
+    int e = enable_trial_lds();
     if (e) return e;
+    if ((e = enable_xcd_lds()) != 0) return e;
   }
   ldc_solver* s = new (std::nothrow) ldc_solver;
   if (!s) return LDC_E_STATE;
@@ -3236,7 +3265,7 @@ int ldc_batch_enqueue(ldc_batch* b, int n_iters, int with_diag, void* stream) {
         xl.gsync = b->d_xsync;
         xl.trials = b->d_xargs[with_diag] + lo;
         HIP_TRY(hipMemsetAsync(b->d_xsync, 0, sizeof(uint32_t) * XG_LEN, st));
-        const int e = xcd_launch_any(xl, s0->p.stage_pressure != 0, with_diag != 0, nwg, s0->n_xcds, st);
+        const int e = xcd_launch_any(xl, s0->p.stage_pressure != 0, with_diag != 0, T, s0->n_xcds, st);
         if (e) return e;
       }
       const PostArgs pdummy = {};
