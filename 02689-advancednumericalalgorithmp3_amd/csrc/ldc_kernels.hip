@@ -2726,7 +2726,7 @@ int xcd_launch_any(const XLaunch& xl, bool sp, bool diag, int T, int n_xcds, hip
   }
 }
 
-// one trial: counters in words [0, XS_LEN) and the launch words in [LDC_SYNC_XLAUNCH, +XG_LEN) of its own sync array
+// one trial: the launch words in [LDC_SYNC_XLAUNCH, +XG_LEN) and the flags in [LDC_SYNC_XFLAGS, +XS_LEN) of its own sync array
 int launch_xcd(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
   const int T = xcd_tiles(s);
   XLaunch xl;
@@ -2734,9 +2734,9 @@ int launch_xcd(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
   xl.B = 1; xl.n_iters = n_iters; xl.slots_per_xcd = 1;
   xl.gsync = s->p.sync + LDC_SYNC_XLAUNCH;
   xl.trials = nullptr;
-  xl.one = make_xargs(s, with_diag, s->p.sync);
-  HIP_TRY(hipMemsetAsync(s->p.sync, 0, sizeof(uint32_t) * LDC_SYNC_GIVEUP, st));
-  HIP_TRY(hipMemsetAsync(s->p.sync + LDC_SYNC_XLAUNCH, 0, sizeof(uint32_t) * XG_LEN, st));
+  xl.one = make_xargs(s, with_diag, s->p.sync + LDC_SYNC_XFLAGS);
+  static_assert(LDC_SYNC_XLAUNCH + XG_LEN <= LDC_SYNC_XFLAGS && LDC_SYNC_XFLAGS + XS_LEN <= LDC_SYNC_LEN, "sync array layout");
+  HIP_TRY(hipMemsetAsync(s->p.sync + LDC_SYNC_XLAUNCH, 0, sizeof(uint32_t) * (LDC_SYNC_XFLAGS + XS_LEN - LDC_SYNC_XLAUNCH), st));
   return xcd_launch_any(xl, s->p.stage_pressure != 0, with_diag != 0, T, s->n_xcds, st);
 }
 

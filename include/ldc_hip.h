@@ -95,8 +95,9 @@ enum {
   LDC_SYNC_HEAD   = 64,  /* one-XCD placement: next tile to be claimed by a work-group of that XCD */
   LDC_SYNC_GIVEUP = 96,  /* set to 1 by a work-group whose bounded wait on the counter ran out    */
   LDC_SYNC_XLAUNCH = 128, /* small-N trial kernel (mode 3): the launch words of a single-trial launch (tickets per XCD,
-                             the trial each XCD slot took); its two barrier counters use words 0 and 32 */
-  LDC_SYNC_LEN    = 2048
+                             the trial each XCD slot took) */
+  LDC_SYNC_XFLAGS = 2048, /* its hand-over flags: three kinds x 32 work-groups, each flag on a 128-byte line of its own */
+  LDC_SYNC_LEN    = 8192
 };
 
 typedef struct ldc_problem {
