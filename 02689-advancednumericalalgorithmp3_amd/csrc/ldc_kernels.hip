@@ -3004,6 +3004,11 @@ int ldc_solver_set_persistent(ldc_solver* s, int mode) {
   return 0;
 }
 
+int ldc_solver_mode(ldc_solver* s) {
+  if (!s) return LDC_E_STATE;
+  return persistent_mode(s);
+}
+
 int ldc_solver_status(ldc_solver* s) {
   if (!s) return LDC_E_STATE;
   if (s->p.sync == nullptr) return 0;

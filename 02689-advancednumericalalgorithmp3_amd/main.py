@@ -130,6 +130,12 @@ def run_batches(groups: list, device: str = None) -> list:
         n = int(cfgs[0]["N"])
         if n_workers > 1 and ((n + 15) // 16) ** 2 >= n_cus:
             parts = len(cfgs)
+        # sizes the small-N trial kernel advances (SG: N <= 79; FSG: the coarse levels, where the time goes) run every
+        # trial on an XCD of its own inside ONE launch: halves on two streams would only take turns at the chip
+        sv = cfgs[0]["solver"]
+        small = n if not sv["_target_"].endswith("FSGSolver") else (n // 2 if int(sv.get("n_levels", 1)) > 1 and n // 2 >= 12 else n)
+        if ((small + 16) // 16) ** 2 <= 25 and int(sv.get("persistent", -1)) in (-1, 3):
+            parts = 1
         cut = [(len(cfgs) * k) // parts for k in range(parts + 1)]
         for k in range(parts):
             weight = max(trial_cost(dict(N=c["N"], Re=c["Re"]), solver=c["solver"].get("_target_", "")) for c in cfgs[cut[k]:cut[k + 1]])
@@ -152,11 +158,9 @@ def run_batches(groups: list, device: str = None) -> list:
                     node = {k: v for k, v in cfg["solver"].items() if k != "_target_"}
                     if device is not None:
                         node["device"] = device
-                    if n_threads > 1 and "persistent" in node:
-                        # a persistent launch needs all its work-groups co-resident; two of them dispatching from two
-                        # worker streams can each hold part of the CUs (or of the elected XCD) and spin until the
-                        # bounded wait gives up (LDC_E_SYNC).  Pool trials therefore run launch by launch.
-                        node["persistent"] = 0
+                    # (launches that need co-resident work-groups -- the small-N trial kernel and the other persistent
+                    #  modes -- are kept from overlapping each other by ldc_lib.resident_lock inside the solvers; the
+                    #  launch-path batches of the other worker streams still run beside them)
                     nodes.append(node)
                 fsg = part[0]["solver"]["_target_"].endswith("FSGSolver")
                 if len(nodes) == 1:                 # alone on its stream: the single-trial kernels (no argument blocks in memory)

@@ -22,7 +22,7 @@ PERSIST_AUTO_TILES = 0      # LDC_PERSIST_AUTO_TILES of include/ldc_hip.h (auto 
 PERSIST_XCD_TILES = 25      # LDC_PERSIST_XCD_TILES: mode 2 (all work-groups of a trial on one XCD) is available up to here
 PERSIST_AUTO_XCD_TILES = 0  # LDC_PERSIST_AUTO_XCD_TILES: auto mode picks mode 2 up to here
 XCD_TILES = 25              # LDC_XCD_TILES: mode 3 (the small-N trial kernel) runs trials of up to ceil(M/16)^2 = 25 tiles
-XCD_AUTO_TILES = 0          # LDC_XCD_AUTO_TILES: auto mode picks mode 3 up to here
+XCD_AUTO_TILES = 25         # LDC_XCD_AUTO_TILES: auto mode picks mode 3 up to here
 REC_REL, REC_RU, REC_RV, REC_RP, REC_E, REC_Z, REC_P, REC_DT = range(8)
 CTRL_DONE, CTRL_ITER = 0, 1
 SCAL_DT, SCAL_UMAX, SCAL_VMAX = 0, 1, 2
@@ -83,6 +83,7 @@ def lib() -> C.CDLL:
     L.ldc_solver_set_graph_iters.argtypes = [_dp, C.c_int]
     L.ldc_solver_set_persistent.argtypes = [_dp, C.c_int]
     L.ldc_solver_status.argtypes = [_dp]
+    L.ldc_solver_mode.argtypes = [_dp]
     L.ldc_stage.argtypes = [_dp, C.c_int, _dp]
     L.ldc_pressure_transform.argtypes = [_dp, C.c_int, _dp]
     L.ldc_diagnostics.argtypes = [_dp, _dp]
@@ -118,12 +119,27 @@ def lib() -> C.CDLL:
 EXPORTS = (
     "ldc_version", "ldc_error_string", "ldc_device_check", "ldc_solver_create", "ldc_solver_destroy",
     "ldc_stage", "ldc_pressure_transform", "ldc_diagnostics", "ldc_finalize", "ldc_prime", "ldc_global_quantities",
-    "ldc_solver_enqueue", "ldc_solver_set_graph_iters", "ldc_solver_set_persistent", "ldc_solver_status",
+    "ldc_solver_enqueue", "ldc_solver_set_graph_iters", "ldc_solver_set_persistent", "ldc_solver_status", "ldc_solver_mode",
     "ldc_residual_debug", "ldc_gemm_nt",
     "ldc_batch_workspace_bytes", "ldc_batch_create", "ldc_batch_destroy", "ldc_batch_enqueue",
     "ldc_poisson_fastdiag", "ldc_vortex_extrema", "ldc_mfma_selftest", "ldc_mfma_peak", "ldc_debug_ablate", "ldc_debug_stamps",
     "ldc_pack", "ldc_stream_priority_range", "ldc_stream_create", "ldc_stream_destroy", "ldc_timing_build",
 )
+
+
+# Launches whose work-groups must all be resident at once (the persistent modes 1-3) must not overlap each other on one
+# device: two of them dispatching from two host threads can each hold part of the CUs (or of an elected XCD) and wait for
+# the rest until the bounded spin gives up (LDC_E_SYNC).  Solvers take this lock around the enqueue + wait of such a chunk;
+# launch-path work of other streams still overlaps with it.
+import threading as _threading
+
+_RESIDENT_LOCKS = {}
+_RESIDENT_GUARD = _threading.Lock()
+
+
+def resident_lock(device_index: int):
+    with _RESIDENT_GUARD:
+        return _RESIDENT_LOCKS.setdefault(int(device_index), _threading.Lock())
 
 
 def check(code: int, what: str = "ldc call"):

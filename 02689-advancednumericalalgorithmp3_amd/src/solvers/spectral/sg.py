@@ -299,6 +299,10 @@ class SGSolver(LidDrivenCavitySolver):
                 mode = 0
             if mode == 3 and ((self.M + 15) // 16) ** 2 > L.XCD_TILES:      # the small-N trial kernel: M <= 80
                 mode = 0
+            if mode == -1 and ((self.M + 15) // 16) ** 2 <= L.XCD_AUTO_TILES and self.device.type == "cuda":
+                n_xcds = max(1, n_cus // 32)
+                if ((self.M + 15) // 16) ** 2 > n_cus // n_xcds:             # (a partitioned device: fewer CUs per XCD)
+                    mode = 0
             L.check(L.lib().ldc_solver_set_persistent(h, mode), "ldc_solver_set_persistent")
         except Exception:
             self.close()
@@ -351,8 +355,14 @@ class SGSolver(LidDrivenCavitySolver):
                 return rows1, done1, end1
             rows2, done2, end2 = self._advance(n_iters - 1)
             return np.concatenate([rows1, rows2], axis=0), done2, end2
-        self._abi("ldc_solver_enqueue", self._handle, n_iters, int(bool(self.params.diagnostics)))
-        self._sync()
+        if n_iters > 1 and L.lib().ldc_solver_mode(self._handle) != 0:
+            # a launch whose work-groups must be co-resident: one at a time per device (ldc_lib.resident_lock)
+            with L.resident_lock(self.device.index or 0):
+                self._abi("ldc_solver_enqueue", self._handle, n_iters, int(bool(self.params.diagnostics)))
+                self._sync()
+        else:
+            self._abi("ldc_solver_enqueue", self._handle, n_iters, int(bool(self.params.diagnostics)))
+            self._sync()
         ctrl = self.d["ctrl"].cpu().numpy()
         end, done = int(ctrl[L.CTRL_ITER]), int(ctrl[L.CTRL_DONE])
         if int(self.d["sync"][L.SYNC_GIVEUP]) != 0:

@@ -215,8 +215,12 @@ int ldc_solver_set_graph_iters(ldc_solver *s, int iters_per_graph);
 #define LDC_PERSIST_XCD_TILES 25        /* one work-group per CU, 32 CUs per XCD, room left for the over-subscription to drain */
 #define LDC_PERSIST_AUTO_XCD_TILES 0
 #define LDC_XCD_TILES 25
-#define LDC_XCD_AUTO_TILES 0
+#define LDC_XCD_AUTO_TILES 25      /* measured faster than the launch path at every size it applies to (profiles/r03_xcd_ab.log) */
 int ldc_solver_set_persistent(ldc_solver *s, int mode);
+/* the mode ldc_solver_enqueue will really use for more than one iteration (0, 1, 2 or 3): what set_persistent asked   */
+/* for, resolved against what the handle's size and device allow.  A host that drives several streams uses it to keep  */
+/* launches that need co-resident work-groups (modes 1-3) from overlapping each other.                                 */
+int ldc_solver_mode(ldc_solver *s);
 /* 0, or LDC_E_SYNC when a persistent launch of this handle gave up a barrier wait (a work-group was not         */
 /* resident): the state is then undefined.  Reads desc->sync on the host: SYNCHRONISES the device.               */
 int ldc_solver_status(ldc_solver *s);

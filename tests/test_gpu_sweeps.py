@@ -49,8 +49,8 @@ def test_config4_batched_sweep_vs_reference_and_oracle(launcher, golden_dir):
     recs = json.loads((root / "sweep_results.json").read_text())
     assert [(r["N"], r["Re"]) for r in recs] == [(64, 400), (64, 1000)]
     assert all(r["metrics"]["iterations"] == 1000 and not r["metrics"]["converged"] for r in recs)
-    # one share group of two on this rank, advanced side by side on the two worker streams
-    assert all(r["solve_group_size"] == 2 and r["solve_streams"] == 2 and r["solve_batch_size"] == 1 for r in recs)
+    # one share group of two on this rank: N=64 runs on the small-N trial kernel, both trials in ONE launch (an XCD each)
+    assert all(r["solve_group_size"] == 2 and r["solve_streams"] == 1 and r["solve_batch_size"] == 2 for r in recs)
     g = np.load(golden_dir / "g4_traj_N64_Re400_K1000.npz")
     u, v = _fields(root / "0", 65)
     assert np.max(np.abs(u - g["u"].reshape(65, 65))) < 1e-12
@@ -79,7 +79,8 @@ def test_config4_grid_shape_n64_to_n256(launcher):
     assert [(r["N"], r["Re"]) for r in recs] == [(n, re) for n in (64, 128, 256) for re in (100, 400, 1000)]
     assert all(r["metrics"]["iterations"] == 40 and r["solve_group_size"] == 3 and r["batch_size"] == 9 for r in recs)
     # N=64 and N=128: a batch of one and a batch of two each; N=256 (a trial fills the chip alone): one by one
-    assert [r["solve_batch_size"] for r in recs] == [1, 2, 2, 1, 2, 2, 1, 1, 1]
+    # N=64: one batch of three on the small-N kernel; N=128: two batches (1 + 2) on two streams; N=256: one by one
+    assert [r["solve_batch_size"] for r in recs] == [3, 3, 3, 1, 2, 2, 1, 1, 1]
     for idx in (1, 5, 6):           # (64, 400), (128, 1000), (256, 100)
         N, Re = recs[idx]["N"], recs[idx]["Re"]
         o = orc.OracleSG(N, float(Re))
@@ -101,7 +102,8 @@ def test_config5_corner_smoothing_search_vs_oracle(launcher):
                            "hydra.sweeper.n_jobs=4", "max_iterations=300", "optuna.objective=botella_vortex"])
     recs = json.loads((root / "sweep_results.json").read_text())
     assert len(recs) == 8 and [r["trial_index"] for r in recs] == [0, 1, 2, 3, 0, 1, 2, 3]
-    assert all(r["solve_group_size"] == 4 and r["solve_batch_size"] == 2 and r["solver"] == "spectral_fsg" for r in recs)
+    # (levels 16 -> 32 both run on the small-N trial kernel: the four trials of a round are ONE batch, an XCD slot each)
+    assert all(r["solve_group_size"] == 4 and r["solve_batch_size"] == 4 and r["solver"] == "spectral_fsg" for r in recs)
     cs = [r["overrides"]["solver.corner_smoothing"] for r in recs]
     assert all(0.01 <= c <= 0.10 for c in cs) and len(set(cs)) == 8
     assert all(r["params"]["corner_smoothing"] == c for r, c in zip(recs, cs))
@@ -144,7 +146,7 @@ def test_two_rank_farm_on_the_gpu(tmp_path):
     a, b = load(two), load(one)
     assert [(x["N"], x["Re"]) for x in a] == [(n, re) for n in (32, 48) for re in (100, 400, 250, 50)]
     assert {x["rank"] for x in a} == {0, 1} and all(x["solve_group_size"] == 2 for x in a)     # two of either size per rank
-    assert all(y["solve_group_size"] == 4 and y["solve_batch_size"] == 2 for y in b)           # one process: four per size
+    assert all(y["solve_group_size"] == 4 and y["solve_batch_size"] == 4 for y in b)           # one process: four per size
     for x, y in zip(a, b):
         assert x["metrics"]["iterations"] == y["metrics"]["iterations"] == 120
         for key in ("final_energy", "final_enstrophy", "final_palinstrophy", "u_momentum_residual", "psi_min"):
@@ -169,8 +171,9 @@ def test_a_failing_batch_costs_only_its_own_trials(tmp_path, monkeypatch, stream
         node.update(kw)
         return {"N": N, "Re": Re, "solver": node}
 
-    g32 = [cfg(32, 100), cfg(32, 400), cfg(32, 250, basis_type="fourier"), cfg(32, 50)]
-    g48 = [cfg(48, 100), cfg(48, 400)]
+    # (persistent=0: on the launch path a share group is cut into two batches; on the small-N kernel it would be one)
+    g32 = [cfg(32, 100, persistent=0), cfg(32, 400, persistent=0), cfg(32, 250, basis_type="fourier", persistent=0), cfg(32, 50, persistent=0)]
+    g48 = [cfg(48, 100, persistent=0), cfg(48, 400, persistent=0)]
     out = mod.run_batches([(g32, [tmp_path / f"a{k}" for k in range(4)]), (g48, [tmp_path / f"b{k}" for k in range(2)])])
     assert [len(x) for x in out] == [4, 2]
     bad = [False, False, True, True] if streams == 2 else [True] * 4       # the batch that holds the fourier trial
