@@ -33,6 +33,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <mutex>
 #include <new>
@@ -2785,9 +2786,15 @@ constexpr hipStreamCaptureMode kCaptureMode = hipStreamCaptureModeRelaxed;
 // The rare, heavy runtime operations of the library -- graph capture and instantiation, destruction of graph
 // executables, the creation-time argument copy of a batch -- run one at a time per process, on ONE private non-blocking
 // stream per device that is created on first use and never destroyed.  Sweeps drive the library from two host threads
-// (solve_concurrently); with a capture stream created and destroyed per handle, a batch being set up in one thread
-// while the other waited on its stream aborted inside the HIP runtime.  The hot calls (graph and kernel launches on
-// the caller's stream) take no lock.  This mutex and these streams are the only process-wide state of the library.
+// (solve_concurrently).  What aborted in round 2 was not this code path by itself: replayed pattern by pattern
+// (tools/probes/stream_race_probe.py, profiles/r03_stream_race_probe.log) per-handle stream creation / capture /
+// instantiation / destruction in one thread runs clean beside another thread's launches, graph replays and STREAM-level
+// waits; the one failing pattern is a DEVICE-wide synchronise in the other thread while a capture is open here --
+// hipDeviceSynchronize returns hipErrorStreamCaptureUnsupported, the open capture is invalidated, and torch ends the process
+// when it meets the stale error in a non-throwing path.  The Python solvers therefore wait on their own stream only
+// (SGSolver._sync); serialising the rare setup operations here keeps captures from ever overlapping each other and costs
+// nothing.  The hot calls (graph and kernel launches on the caller's stream) take no lock.  This mutex and these streams are
+// the only process-wide state of the library.
 std::mutex g_setup_mutex;
 hipStream_t g_setup_stream[64] = {};
 hipError_t setup_stream(hipStream_t* out) {      // call with g_setup_mutex held
@@ -2815,12 +2822,47 @@ hipError_t copy_now(void* dst, const void* src, size_t bytes, hipMemcpyKind kind
   return e != hipSuccess ? e : w;
 }
 
+#ifdef LDC_TIMING
+// Timing probe (instrumented build, LDC_FORK_PROBE=1; RESULTS ARE WRONG): the iteration captured as a FORKED graph -- after
+// stage 3 the post launch goes to a side branch beside stage 4 instead of behind it.  The branch reads what stage 4 is
+// still writing (the real thing would need a div(u3) -> p kernel in front of the transforms), so only the TIMING means
+// anything: it answers whether a second launch finds room beside the 256 x 512-thread work-groups of stage 4 at all.
+int launch_iteration_forked(ldc_solver* s, int with_diag, hipStream_t st, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
+  int e;
+  for (int k = 0; k < 3; ++k) if ((e = launch_stage(s, k, with_diag, st)) != 0) return e;
+  HIP_TRY(hipEventRecord(fork, st));
+  HIP_TRY(hipStreamWaitEvent(side, fork, 0));
+  if ((e = launch_stage(s, 3, with_diag, st)) != 0) return e;
+  if ((e = launch_post(s, s->p.P, 0, 1, with_diag, side)) != 0) return e;
+  HIP_TRY(hipEventRecord(join, side));
+  HIP_TRY(hipStreamWaitEvent(st, join, 0));
+  return 0;
+}
+#endif
+
 int build_graph(ldc_solver* s, int with_diag) {
   std::lock_guard<std::mutex> lock(g_setup_mutex);
   HIP_TRY(setup_stream(&s->capture_stream));
   hipGraph_t g = nullptr;
+#ifdef LDC_TIMING
+  static hipStream_t side = nullptr;
+  static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  const char* fp = getenv("LDC_FORK_PROBE");
+  const bool forked = fp != nullptr && fp[0] == '1' && s->p.stage_pressure == 0;
+  if (forked && side == nullptr) {
+    HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
+#endif
   HIP_TRY(hipStreamBeginCapture(s->capture_stream, kCaptureMode));
   int e = 0;
+#ifdef LDC_TIMING
+  if (forked) {
+    for (int it = 0; it < s->iters_per_graph && e == 0; ++it)
+      e = launch_iteration_forked(s, with_diag, s->capture_stream, side, ev_fork, ev_join);
+  } else
+#endif
   for (int it = 0; it < s->iters_per_graph && e == 0; ++it) e = launch_iteration(s, with_diag, s->capture_stream);
   hipError_t ce = hipStreamEndCapture(s->capture_stream, &g);
   if (e != 0) { if (g) (void)hipGraphDestroy(g); return e; }

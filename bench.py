@@ -371,7 +371,12 @@ def main():
                 "per_gpu": [float(r) for r in rates], "iterations_timed_per_trial": n_it,
                 "streams": max(1, min(int(os.environ.get("LDC_BATCH_STREAMS", "3")), 2, fB)),
                 "workload": f"{fB} SG trials of N={fN} per GPU as main.py advances the trials a rank owns: two batches with "
-                            "shared launches on two HIP streams (step()-only loop)"}
+                            "shared launches on two HIP streams (step()-only loop)",
+                "meaning": "throughput of INDEPENDENT trials (a grid sweep, or one round of a search): this is what scales with "
+                           "the number of GPUs.  A model-based search scales by rounds(1 GPU) / rounds(N GPUs) only: the sampler "
+                           "learns between rounds, main.py never plans fewer than three (search_mode=throughput; config 5: 8 -> 3 "
+                           "rounds, at most 2.7x) and offers the reference's own ask-n_jobs / tell-n_jobs sequence as "
+                           "search_mode=reference (no scaling beyond batching) -- DESIGN.md 3"}
 
     out = None
     if rank == 0:
