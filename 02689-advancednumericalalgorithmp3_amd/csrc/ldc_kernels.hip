@@ -304,11 +304,18 @@ struct FinalArgs {
   double* rec;
 };
 
+// the two halves of the denominator of the CFL step (sg.py:387-408), separately: fin_decide_wave evaluates them on two lanes
+// side by side (each is a square root and two divisions in a row)
+__device__ __forceinline__ double dt_lambda_x(double umax, const FinalArgs& a) {
+  const double um = fmax(umax, a.lid);
+  return (um + sqrt(nm_madd(um, um, a.beta2))) / a.hx + a.nu / (a.hx * a.hx);
+}
+__device__ __forceinline__ double dt_lambda_y(double vmax, const FinalArgs& a) {
+  const double vm = fmax(vmax, 1e-10);
+  return (vm + sqrt(nm_madd(vm, vm, a.beta2))) / a.hy + a.nu / (a.hy * a.hy);
+}
 __device__ __forceinline__ double next_dt(double umax, double vmax, const FinalArgs& a) {
-  const double um = fmax(umax, a.lid), vm = fmax(vmax, 1e-10);
-  const double lx = (um + sqrt(nm_madd(um, um, a.beta2))) / a.hx + a.nu / (a.hx * a.hx);
-  const double ly = (vm + sqrt(nm_madd(vm, vm, a.beta2))) / a.hy + a.nu / (a.hy * a.hy);
-  return a.cfl / (lx + ly);
+  return a.cfl / (dt_lambda_x(umax, a) + dt_lambda_y(vmax, a));
 }
 
 // Control block of one trial inside the persistent trial kernel (LDS; every work-group keeps its own, identical copy:
@@ -380,14 +387,22 @@ __device__ __forceinline__ FinOut fin_decide_wave(const FinalArgs& a, const doub
     xr = total(lane);
     xs = (lane < PS_RP2 + 1) ? sqrt(xr) : 0.0;     // DU2, DV2, U02, V02, RU2, RV2, RP2
   } else if (lane == 16 && crit) {
-    xr = next_dt(total(PS_UMAX), total(PS_VMAX), a);
+    xr = dt_lambda_x(total(PS_UMAX), a);
+  } else if (lane == 17 && crit) {
+    xr = dt_lambda_y(total(PS_VMAX), a);
   }
   double r[PS_N + 2], sq[PS_RP2 + 1];
 #pragma unroll
   for (int q = 0; q < PS_N + 2; ++q) r[q] = lane_value(xr, q);
 #pragma unroll
   for (int q = 0; q < PS_RP2 + 1; ++q) sq[q] = lane_value(xs, q);
-  const double dt_new = lane_value(xr, 16);
+  // the three divisions that remain -- the two relative changes and cfl / (lambda_x + lambda_y) -- by three lanes at once
+  // (one after the other on every lane they were ~900 cycles of the fold's tail); the same operations, the same rounding
+  const double lxy = lane_value(xr, 16) + lane_value(xr, 17);
+  const double num = (lane == 0) ? sq[PS_DU2] : (lane == 1) ? sq[PS_DV2] : a.cfl;
+  const double den = (lane == 0) ? (sq[PS_U02] + 1e-12) : (lane == 1) ? (sq[PS_V02] + 1e-12) : lxy;
+  const double quo = num / den;
+  const double dt_new = lane_value(quo, 2);
   FinOut o;
   o.latch = 0; o.iter = iter; o.flushed = flushed; o.dt = dt_cur; o.umax = 0.0; o.vmax = 0.0;
   const bool w0 = writer && lane == 0;
@@ -400,8 +415,8 @@ __device__ __forceinline__ FinOut fin_decide_wave(const FinalArgs& a, const doub
     o.flushed = iter;
   }
   if (crit) {
-    const double relu = sq[PS_DU2] / (sq[PS_U02] + 1e-12);
-    const double relv = sq[PS_DV2] / (sq[PS_V02] + 1e-12);
+    const double relu = lane_value(quo, 0);
+    const double relv = lane_value(quo, 1);
     // Python's max(a, b) returns a unless b > a: a NaN in relv is dropped, one in relu sticks
     const double rel = (relv > relu) ? relv : relu;
     if (w0) {
@@ -2692,7 +2707,10 @@ XArgs make_xargs(const ldc_solver* s, int with_diag, unsigned* sync) {
   a.VK[0] = p.VK; a.VK[1] = p.VAK; a.VK[2] = p.VBK;
   a.VTK[0] = p.VTK; a.VTK[1] = p.VATK; a.VTK[2] = p.VBTK;
   a.PK[0] = p.PK; a.PK[1] = p.PAK; a.PK[2] = p.PBK;
-  a.T1TK = p.T1TK; a.T2TK = p.T2TK; a.WK = p.WK; a.WTK = p.WTK;
+  a.PTK[0] = p.T1TK; a.PTK[1] = p.T2TK; a.PTK[2] = p.WTK;     // borrowed (SG uses [0] only, the smoother carries no omega)
+  a.WK = p.WK; a.WTK = p.WTK;
+  a.GxF = p.GxF; a.GyF = p.GyF; a.IxF = p.IxF; a.IyF = p.IyF;
+  a.ring = reinterpret_cast<double*>(p.sync + LDC_SYNC_XRING);
   a.part4 = p.partials; a.partZ0 = p.partials + p.partials_stride; a.partP0 = p.partials + 3 * p.partials_stride;
   a.stride = p.partials_stride;
   a.fin = make_final_args(s, with_diag, 1);
@@ -2736,7 +2754,8 @@ int launch_xcd(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
   xl.gsync = s->p.sync + LDC_SYNC_XLAUNCH;
   xl.trials = nullptr;
   xl.one = make_xargs(s, with_diag, s->p.sync + LDC_SYNC_XFLAGS);
-  static_assert(LDC_SYNC_XLAUNCH + XG_LEN <= LDC_SYNC_XFLAGS && LDC_SYNC_XFLAGS + XS_LEN <= LDC_SYNC_LEN, "sync array layout");
+  static_assert(LDC_SYNC_XLAUNCH + XG_LEN <= LDC_SYNC_XFLAGS && LDC_SYNC_XFLAGS + XS_LEN <= LDC_SYNC_XRING &&
+                LDC_SYNC_XRING + 2 * kXT * kXT * 64 <= LDC_SYNC_LEN, "sync array layout");
   HIP_TRY(hipMemsetAsync(s->p.sync + LDC_SYNC_XLAUNCH, 0, sizeof(uint32_t) * (LDC_SYNC_XFLAGS + XS_LEN - LDC_SYNC_XLAUNCH), st));
   return xcd_launch_any(xl, s->p.stage_pressure != 0, with_diag != 0, T, s->n_xcds, st);
 }

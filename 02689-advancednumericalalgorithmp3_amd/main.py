@@ -118,9 +118,7 @@ def run_batches(groups: list, device: str = None) -> list:
     import threading
     from solvers.spectral.batched import BatchedFSGSolver, BatchedSGSolver, run_concurrently
     n_workers = max(1, int(os.environ.get("LDC_BATCH_STREAMS", "3")))
-    import torch
-    n_cus = torch.cuda.get_device_properties(torch.device(device) if device is not None
-                                             else torch.cuda.current_device()).multi_processor_count
+    n_cus = 256              # an MI355X; only decides whether a size fills the chip on its own (N >= 241) -- no device query here
     tasks = []
     for gi, (cfgs, _) in enumerate(groups):
         parts = max(1, min(2, n_workers, len(cfgs)))      # halves: more, smaller batches measured no better (N=128)

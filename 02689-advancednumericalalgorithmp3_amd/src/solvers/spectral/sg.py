@@ -162,6 +162,14 @@ class SGSolver(LidDrivenCavitySolver):
 
         IxF = np.zeros((M, M)); IxF[:, 1:-1] = self.Interp_x
         IyF = np.zeros((M, M)); IyF[:, 1:-1] = self.Interp_y
+        # The interpolant through the inner nodes evaluated AT an inner node is that node's value: rows 1 .. M-2 are unit
+        # rows up to the rounding of V_full V_inner^-1 (1e-15).  They are set exactly (include/ldc_hip.h: the small-N trial
+        # kernel contracts GxF with p itself off the ring); anything but rounding there would be a different operator.
+        for F in (IxF, IyF):
+            inner = F[1:-1, 1:-1]
+            if np.max(np.abs(inner - np.eye(M - 2))) > 1e-9:
+                raise ValueError("inner-to-full interpolation is not the identity on the inner nodes")
+            inner[...] = np.eye(M - 2)
         for name, a in (("Dx", self.Dx_1d), ("D2x", self.Dxx_1d), ("Dy", self.Dy_1d), ("D2y", self.Dyy_1d),
                         ("IxF", IxF), ("GxF", self.Dx_1d @ IxF), ("IyF", IyF), ("GyF", self.Dy_1d @ IyF)):
             up(name, a)
@@ -291,19 +299,16 @@ class SGSolver(LidDrivenCavitySolver):
         try:
             L.check(L.lib().ldc_solver_set_graph_iters(h, int(self.params.graph_iters)), "ldc_solver_set_graph_iters")
             mode = int(self.params.persistent)
-            # A persistent mode on a size it cannot run (mode 2: more tiles than one XCD holds; mode 1: more tiles than
-            # the device has CUs, e.g. the fine level of a hierarchy) falls back to the launch path -- both the same way:
-            # a configuration asks for "persistent where it applies", the levels of one FSG solve differ in size.
-            n_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
-            if (mode == 2 and self.T * self.T > L.PERSIST_XCD_TILES) or (mode == 1 and self.T * self.T > n_cus):
-                mode = 0
-            if mode == 3 and ((self.M + 15) // 16) ** 2 > L.XCD_TILES:      # the small-N trial kernel: M <= 80
-                mode = 0
-            if mode == -1 and ((self.M + 15) // 16) ** 2 <= L.XCD_AUTO_TILES and self.device.type == "cuda":
-                n_xcds = max(1, n_cus // 32)
-                if ((self.M + 15) // 16) ** 2 > n_cus // n_xcds:             # (a partitioned device: fewer CUs per XCD)
-                    mode = 0
-            L.check(L.lib().ldc_solver_set_persistent(h, mode), "ldc_solver_set_persistent")
+            # A persistent mode on a size it cannot run (mode 2 / 3: more tiles than one XCD holds; mode 1: more tiles than
+            # the device has CUs, e.g. the fine level of a hierarchy) falls back to the launch path -- all the same way:
+            # a configuration asks for "persistent where it applies", the levels of one FSG solve differ in size.  The
+            # library knows the device (CUs, XCDs) and says LDC_E_ARG; nothing is asked of torch here: this runs in the
+            # worker threads of a sweep, where torch.cuda.get_device_properties raced inside torch's device bookkeeping
+            # ("Invalid device id" once, a process abort another time: round 3, test_gpu_config5_shape_batched_fsg_vs_oracle).
+            rc = L.lib().ldc_solver_set_persistent(h, mode)
+            if rc == -1 and mode in (1, 2, 3):
+                rc = L.lib().ldc_solver_set_persistent(h, 0)
+            L.check(rc, "ldc_solver_set_persistent")
         except Exception:
             self.close()
             self._handle_key = None

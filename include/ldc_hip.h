@@ -96,8 +96,9 @@ enum {
   LDC_SYNC_GIVEUP = 96,  /* set to 1 by a work-group whose bounded wait on the counter ran out    */
   LDC_SYNC_XLAUNCH = 128, /* small-N trial kernel (mode 3): the launch words of a single-trial launch (tickets per XCD,
                              the trial each XCD slot took) */
-  LDC_SYNC_XFLAGS = 2048, /* its hand-over flags: three kinds x 32 work-groups, each flag on a 128-byte line of its own */
-  LDC_SYNC_LEN    = 8192
+  LDC_SYNC_XFLAGS = 2048, /* its hand-over flags: 32 work-groups, each flag on a 128-byte line of its own */
+  LDC_SYNC_XRING  = 8192, /* its scratch for the boundary ring of grad p: 25 tiles x 64 doubles */
+  LDC_SYNC_LEN    = 16384
 };
 
 typedef struct ldc_problem {
@@ -122,6 +123,9 @@ typedef struct ldc_problem {
   const double *Dx, *D2x, *Dy, *D2y;   /* sg.py:188-193                                */
   const double *IxF, *GxF;  /* Interp_x embedded in full indexing; Dx @ IxF  (sg.py:209, 270-275) */
   const double *IyF, *GyF;  /* Interp_y embedded;                  Dy @ IyF  (sg.py:210, 270-276) */
+                            /* Rows 1 .. M-2 of IxF / IyF must be UNIT rows (the interpolant through the inner nodes,    */
+                            /* evaluated at an inner node, is that node's value: the reference's matrices are, to        */
+                            /* rounding; the host sets them exactly): mode 3 uses d/dx p = GxF p off the ring columns.   */
   const double *wx, *wy;    /* quadrature weights, length LD       (sg.py:489-490)     */
   const double *ulid;       /* lid profile u_lid(x_i), length LD   (corner.py:80-112)  */
   const double *DxL, *D2xL, *DyL, *D2yL; /* column M-1 of Dx, D2x, Dy, D2y as contiguous length-LD vectors */

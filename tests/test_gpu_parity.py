@@ -84,9 +84,14 @@ def test_single_residual_vs_oracle(N):
     bound["R_v"] = A(o.u) * bound["dv_dx"] + A(o.v) * bound["dv_dy"] + bound["dp_dy"] + nu * bound["lap_v"]
     bound["R_p"] = (5.0 * (bound["du_dx"] + bound["dv_dy"]))[1:-1, 1:-1]
     want = dict(parts, R_u=Ru, R_v=Rv, R_p=Rp)
+    # The pressure terms get a larger constant: the reference's inner-to-full interpolation matrices are unit rows on the
+    # inner nodes only up to the rounding of V_full V_inner^-1 (|I - 1| <= 4e-15 = 16 eps at these sizes, measured), the
+    # build sets those rows exactly (include/ldc_hip.h) -- a difference of a few eps |Dx| |p| in grad p.
+    const = dict(dp_dx=24, dp_dy=24, R_u=24, R_v=24)
     for key, val in want.items():
         err = np.abs(got[key] - val.ravel())
-        assert np.all(err <= 4 * eps * bound[key].ravel() + 1e-300), (key, err.max(), (4 * eps * bound[key]).max())
+        c = const.get(key, 4)
+        assert np.all(err <= c * eps * bound[key].ravel() + 1e-300), (key, err.max(), (c * eps * bound[key]).max())
 
 
 TRAJ = [(16, 100, 50), (32, 100, 500), (64, 400, 1000), (64, 1000, 3000)]

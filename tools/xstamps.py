@@ -37,7 +37,7 @@ names = ["entry", "frags req", "contr done", "barrier", "epilogue", "barrier", "
 for k in range(4):
     base = st[:, 0, k, 0][:, None]
     print(f"-- stage {k + 1}: length (wave 0 entry -> next entry) median {np.median(st[:, 0, k, 10] - st[:, 0, k, 0]):.0f} cycles")
-    for wv in (0, 2, 4, 6):
+    for wv in (0, 2, 4, 6, 7):
         row = []
         for p in range(11):
             x = st[:, wv, k, p] - base[:, 0]
