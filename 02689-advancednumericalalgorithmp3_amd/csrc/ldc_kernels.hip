@@ -2471,9 +2471,8 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
   return a;
 }
 
-// dynamic LDS above 64 KiB has to be enabled per kernel and device (hipFuncSetAttribute).  The library keeps no
-// process-wide state: ldc_solver_create / ldc_batch_create do it for every variant on the device that is current
-// there (the handle's device, checked again at every enqueue), so a launch itself touches nothing but its arguments.
+// dynamic LDS above 64 KiB has to be enabled per kernel and device (hipFuncSetAttribute): done once per device by the
+// first ldc_solver_create / ldc_batch_create there (ensure_kernel_attributes), so a launch itself touches nothing but its arguments.
 template <bool GP, bool LAST, bool DUMP, bool BATCH, int DIAG>
 int enable_stage_lds() {
   return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(stage_kernel<GP, LAST, DUMP, BATCH, DIAG>),
@@ -2841,6 +2840,27 @@ hipError_t copy_now(void* dst, const void* src, size_t bytes, hipMemcpyKind kind
   return e != hipSuccess ? e : w;
 }
 
+// Dynamic LDS above 64 KiB has to be enabled per kernel and device (hipFuncSetAttribute).  ONCE per device and process, under
+// the setup mutex, before the first handle of that device exists -- not at every create: a sweep creates handles in one host
+// thread while another launches the same kernels, and an attribute being rewritten under a launch that needs it (the small-N
+// trial kernel asks for 70 KB, the stage kernels for up to 107 KB) ended the process with a hardware exception once in a
+// while (round 3: tests/test_fsg.py::test_gpu_config5_shape_batched_fsg_vs_oracle aborted in two full-suite runs, never alone
+// and never with the runtime's logging on -- and quite possibly what round 2 met before its captures were serialised).
+bool g_attrs_done[64] = {};
+int ensure_kernel_attributes() {
+  std::lock_guard<std::mutex> lock(g_setup_mutex);
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+  if (g_attrs_done[dev]) return 0;
+  int e;
+  if ((e = enable_stage_lds_all<false>()) != 0 || (e = enable_stage_lds_all<true>()) != 0 || (e = enable_trial_lds()) != 0 ||
+      (e = enable_xcd_lds()) != 0)
+    return e;
+  g_attrs_done[dev] = true;
+  return 0;
+}
+
 #ifdef LDC_TIMING
 // Timing probe (instrumented build, LDC_FORK_PROBE=1; RESULTS ARE WRONG): the iteration captured as a FORKED graph -- after
 // stage 3 the post launch goes to a side branch beside stage 4 instead of behind it.  The branch reads what stage 4 is
@@ -3009,14 +3029,11 @@ int ldc_solver_create(const ldc_problem* d, ldc_solver** out) {
   for (const void* q : req) if (bad_ptr(q)) return LDC_E_ARG;
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
-  { const int e = enable_stage_lds_all<false>(); if (e) return e; }
+  { const int e = ensure_kernel_attributes(); if (e) return e; }
   int n_cus = 0;
   HIP_TRY(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev));
   if (d->sync != nullptr) {
     if ((reinterpret_cast<uintptr_t>(d->sync) & 255) != 0) return LDC_E_ARG;
-    int e = enable_trial_lds();
-    if (e) return e;
-    if ((e = enable_xcd_lds()) != 0) return e;
   }
   ldc_solver* s = new (std::nothrow) ldc_solver;
   if (!s) return LDC_E_STATE;
@@ -3215,7 +3232,7 @@ int ldc_batch_create(ldc_solver* const* solvers, int n_trials, void* workspace, 
         t->n_pedge_blocks != s0->n_pedge_blocks || t->device != s0->device)
       return LDC_E_ARG;
   }
-  { int e = on_own_device(s0); if (e) return e; if ((e = enable_stage_lds_all<true>()) != 0) return e; }
+  { int e = on_own_device(s0); if (e) return e; if ((e = ensure_kernel_attributes()) != 0) return e; }
   ldc_batch* b = new (std::nothrow) ldc_batch;
   if (!b) return LDC_E_STATE;
   b->B = n_trials;
