@@ -1398,705 +1398,13 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// persistent trial kernel: every iteration of one trial inside ONE launch
-// ---------------------------------------------------------------------------------------
-// A trial of T x T tiles with T*T work-groups (at most one per CU, all resident) needs no launch boundary between its
-// RK stages: work-group (I, J) keeps its tile for the whole launch and the stages are separated by a counter barrier
-// among the trial's own work-groups.  What a launch-per-stage iteration pays per stage at small N -- a dependent
-// dispatch, the ramp of a new grid, cold kernel-argument and operand misses: five launches of ~7 us for 16 work-groups
-// at N = 64 -- shrinks to one barrier (an atomic add and a poll) per phase.  Data crosses work-groups in the form the
-// guide measures as valid without fences (MI355X_MICROARCH.md, visibility, valid forms row 1): write-through (sc1)
-// stores, every storing wave's vmcnt(0), work-group barrier, one lane's agent-scope add; one lane's sc1 poll,
-// work-group barrier, sc1 loads only.  The arithmetic is the launch path's, instruction for instruction
-// (stage_body / fin_work with PERSIST, post_phase = the T tiles of post_kernel), so records and fields are
-// bit-identical to it (tests/test_gpu_persistent.py).
-//
-// Phases of one iteration: stage 1 | stage 2 | stage 3 | stage 4 | finalize (EVERY work-group folds the partial sums
-// itself, in the same fixed order: dt and the latch need no broadcast) + pressure transforms; in smoother mode a
-// transform phase follows each of stages 1-3 as well.  A barrier closes every phase.
-struct TrialArgs {
-  StageArgs st[4];
-  PostArgs post;                 // transforms of p^(n+1); post.fin: the finalize arguments
-  const double* Pst[3];          // smoother mode: the stage pressure whose transforms follow stage 1, 2, 3 (PA, PB, PA)
-  const double* PstK[3];
-  int n_iters;
-  int local;                     // one-XCD placement (mode 2): tiles are claimed by the work-groups of ONE XCD, see trial_kernel
-  int nt;                        // work-groups that carry a tile (T * T); the launch may be larger (local)
-  unsigned* sync;                // [0] arrival counter, [LDC_SYNC_GIVEUP] set when a spin gave up; zeroed before the launch
-  double* stamps;                // timing experiments (ldc_debug_stamps): 64 doubles per work-group, or null
-};
-static_assert(sizeof(TrialArgs) <= 4096, "TrialArgs must fit the kernel-argument segment");
-
+// spins of the persistent kernels give up after this long, so that a grid always drains
 constexpr unsigned long long kSpinLimitTicks = 200000000ull;    // 2 s of the 100 MHz s_memrealtime counter
-
-// Barrier among the `nwg` work-groups of this launch; `phase` counts the barriers passed (monotonic counter: no reset,
-// no generation flip).  Returns false when the wait was given up (a peer is not resident or has left): every thread
-// of the work-group sees the same answer and the kernel ends.
-__device__ __forceinline__ bool grid_sync(unsigned* sync, unsigned& phase, unsigned nwg, int tid, TrialState* S,
-                                          const bool local) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have left (write-through: the chip; local: the L2)
-  __syncthreads();
-  ++phase;
-  if (tid == 0) {
-    LDC_GLOBAL unsigned* ctr = (LDC_GLOBAL unsigned*)sync;
-    const unsigned target = phase * nwg;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    if (local) {
-      // every participant sits on ONE XCD: the counter lives in that XCD's L2 -- adds and polls are L2 atomics
-      // without sc1 (an sc1 atomic is executed behind the fabric and drops the line from the L2)
-      // (the poll is a returning atomic OR of zero written in asm: as a builtin hipcc turns an idempotent
-      //  read-modify-write into a plain load, which the CU's L1 would serve -- stale for ever)
-      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      auto peek = [&]() {
-        unsigned r;
-        const unsigned zero = 0u;
-        asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(ctr), "v"(zero) : "memory");
-        return r;
-      };
-      while (peek() < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinLimitTicks) {
-          S->abort = 1;
-          __hip_atomic_store(ctr + LDC_SYNC_GIVEUP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-    } else {
-      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinLimitTicks) {
-          S->abort = 1;
-          __hip_atomic_store(ctr + LDC_SYNC_GIVEUP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  return S->abort == 0;
-}
-
-// T1T / T2T of the pressure array P (packed twin PK) as a phase of the persistent kernel: tile (I, J) by waves 0-3
-// with the K split, the order of the sums and the stores of post_kernel's T tiles; the rows of index M-1 (tail) by
-// waves 4-7, one wave per k like post_kernel's edge blocks.  All kStageThreads threads call.
-__device__ __forceinline__ void post_phase(const PostArgs& a, const double* P, const double* PK, int bx, int nblk,
-                                           double* red, int tid, const int wt) {
-  const int lane = tid & 63, wv = tid >> 6;
-  const int M = a.M, LD = a.LD, T = a.T, m1 = M - 1;
-  const bool tile_wave = wv < kWaves;
-  int I, J;
-  tile_of_block(bx, T, I, J);
-  const int r0 = 16 * I, c0 = 16 * J;
-  if (tile_wave) {
-    v4d acc[2] = {(v4d){0, 0, 0, 0}, (v4d){0, 0, 0, 0}};
-    for (int g = wv; g < T; g += kWaves) {
-      const v4d gP = ldpk_t<true>(PK, a.NB, I, g, lane);
-      const v4d gI = ldpk_t<true>(a.IyFK, a.NB, J, g, lane), gG = ldpk_t<true>(a.GyFK, a.NB, J, g, lane);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc[0] = MFMA_F64(gP[s], gI[s], acc[0]);
-        acc[1] = MFMA_F64(gP[s], gG[s], acc[1]);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[((wv * 2 + q) * 4 + r) * 64 + lane] = acc[q][r];
-  } else if (a.tail) {
-    for (int k = bx * kWaves + (wv - kWaves); k < M; k += nblk * kWaves) {
-      const double* pk = P + (size_t)k * LD;
-      double t1, t2;
-      dot_rows2<true>(pk, a.IyF + (size_t)m1 * LD, a.GyF + (size_t)m1 * LD, M, lane, t1, t2);
-      if (lane == 0) { st_out(a.T1T + (size_t)m1 * LD + k, t1, wt); st_out(a.T2T + (size_t)m1 * LD + k, t2, wt); }
-    }
-  }
-  __syncthreads();
-  double s[2] = {0.0, 0.0};
-  if (tile_wave) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      double x = red[((0 * 2 + q) * 4 + wv) * 64 + lane];
-      x += red[((1 * 2 + q) * 4 + wv) * 64 + lane];
-      x += red[((2 * 2 + q) * 4 + wv) * 64 + lane];
-      x += red[((3 * 2 + q) * 4 + wv) * 64 + lane];
-      s[q] = x;
-    }
-  }
-  __syncthreads();
-  double* t1 = red;
-  double* t2 = red + 16 * 17;
-  if (tile_wave) {
-    const int ti = 4 * wv + (lane >> 4), tj = lane & 15;
-    t1[ti * 17 + tj] = s[0];
-    t2[ti * 17 + tj] = s[1];
-  }
-  __syncthreads();
-  if (tile_wave) {
-    // Only the packed twins, block (J, I), 16 bytes per store: threads 0..127 T1T, 128..255 T2T (thread h of a half
-    // stores doubles 2h, 2h+1 of the 2-KB block = elements (row pr, columns pc, pc+1)).  The row-major tile body of
-    // T1T / T2T has no reader (the fragments come from the twins, the index-(M-1) jobs read row M-1 only).
-    (void)LD;
-    const int hh = tid & 127, pl = hh >> 1, pr = pl & 15, pc = 4 * (pl >> 4) + 2 * (hh & 1);
-    const size_t kbT = ((size_t)(J * a.NB + I) << 8) + 2 * hh;
-    const bool ok0 = (c0 + pr < M) && (r0 + pc < M), ok1 = (c0 + pr < M) && (r0 + pc + 1 < M);
-    const double* tt = tid < 128 ? t1 : t2;
-    st_out2((tid < 128 ? a.T1TK : a.T2TK) + kbT, ok0 ? tt[pc * 17 + pr] : 0.0, ok1 ? tt[(pc + 1) * 17 + pr] : 0.0, wt);
-  }
-}
-
-// ---- tile-resident stage ------------------------------------------------------------------------------------
-// Inside the persistent kernel a work-group owns tile (I, J) for the whole launch, so everything that belongs to the
-// tile alone STAYS in the work-group: a thread keeps phi^n, its stage input, grad p^n and p^n of its node in
-// registers from stage to stage and from iteration to iteration; the constants of the epilogue (quadrature weights,
-// lid profile, last operator columns, boundary values of index M-1) sit in LDS tables filled once; the constant
-// rows of index M-1 that feed the index-(M-1) jobs are staged in LDS once.  Per stage a work-group then issues only
-// the loads that are communication -- the operand fragments of other tiles' state (sc1) -- and only the stores other
-// work-groups read: the packed twins of its tile (16-byte write-through stores), p row-major (the transforms' edge
-// rows read it), omega on the row / column of index M-1, its partial sums.  The launch body issues ~230 vector-memory
-// instructions per work-group and stage, most of them pointwise 8-byte accesses to the tile's own data, and that
-// issue rate is what bounds it at small N (profiles/r02_persist_v0_stamps.log); here it is ~70.
-// The row-major forms of phi are written once, when the launch ends.
-// The arithmetic -- K split over the eight waves, order of every sum, every formula of the epilogue -- is stage_body's,
-// so a trajectory is bit-identical to the launch path's (tests/test_gpu_persistent.py).
-enum { TB_DXL = 0, TB_D2XL, TB_LID, TB_WX, TB_UN, TB_VN, TB_DYL, TB_D2YL, TB_WY, TB_UE, TB_VE, TB_N };
-constexpr int kTabStride = 24;          // 17 entries used: 16 of the tile + index M-1
-constexpr int kTileSlots = 8;           // rows of index M-1 per wave: A0 A1 A2 B0 B1 B2 (as StageLds) + omega row / column
-
-struct TileLds {
-  static constexpr int NA = 5;
-  static constexpr int RED = kStageWaves * NA * 4 * 64;
-  static constexpr int EDGE = RED;                                    // [wave][15][16]
-  static constexpr int TILE = EDGE + kStageWaves * 15 * 16;           // 4 x 16 x 17 (u, v, omega, p)
-  static constexpr int SCR = TILE + 4 * 16 * 17;
-  static constexpr int EROW = SCR + kStageWaves * PS_N;               // [wave][kTileSlots][4 groups][16]
-  static constexpr int TAB = EROW + kStageWaves * kTileSlots * 64;    // [TB_N][kTabStride]
-  static constexpr int WEN = TAB + TB_N * kTabStride;                 // omega at (M-1, j) and (i, M-1): [2][kTabStride]
-  static constexpr int TOTAL = WEN + 2 * kTabStride;
-  static constexpr size_t BYTES = sizeof(double) * TOTAL;
-};
-static_assert(TileLds::BYTES <= kLdsLimit - 1024, "tile-resident kernel LDS (plus its static words)");
-
-struct TileCtx {
-  // tile and thread geometry
-  int M, LD, T, NB, tail, m1, I, J, r0, c0;
-  int tid, lane, wv, role, kq, ng;
-  int wt;                                // stores other work-groups read: 1 write-through (sc1), 0 plain (one-XCD placement)
-  bool rowE, colE, cornE, anyE;          // block-uniform: which index-(M-1) job this tile carries
-  bool owner, edge_thr, colnode;
-  int ekind, eidx, i, j, ti, tj, tabi, tabj;
-  // the node's state, resident
-  double u0, v0, p0;                     // phi^n
-  double uc, vc;                         // stage input (= output of the previous stage)
-  double px, py;                         // grad p^n (SG: of stage 1, used by stages 2-4)
-};
-
-__device__ __forceinline__ void tile_setup(TileCtx& c, const StageArgs& a, int bx, double* lds) {
-  c.M = a.M; c.LD = a.LD; c.T = a.T; c.NB = a.NB; c.tail = a.tail; c.m1 = a.M - 1;
-  c.tid = threadIdx.x; c.lane = c.tid & 63; c.wv = c.tid >> 6; c.role = c.wv >> 2; c.kq = c.wv & 3;
-  c.ng = (c.T - c.kq + 3) / 4;
-  tile_of_block(bx, c.T, c.I, c.J);
-  c.r0 = 16 * c.I; c.c0 = 16 * c.J;
-  const bool etile = a.tail != 0;
-  c.rowE = etile && (c.I == c.J);
-  c.colE = etile && (c.J == (c.I + 1) % c.T);
-  c.cornE = etile && (c.T >= 3 ? (c.I == 0 && c.J == 2) : (c.I == 0 && c.J == 0));
-  c.anyE = c.rowE || c.colE || c.cornE;
-  c.ti = 4 * (c.wv & 3) + (c.lane >> 4); c.tj = c.lane & 15;
-  c.owner = c.tid < 256;
-  c.ekind = (c.tid - 256) >> 4; c.eidx = (c.tid - 256) & 15;
-  c.edge_thr = !c.owner && ((c.ekind == 0 && c.rowE) || (c.ekind == 1 && c.colE) || (c.ekind == 2 && c.eidx == 0 && c.cornE));
-  c.i = c.owner ? (c.r0 + c.ti) : ((c.ekind == 1) ? (c.r0 + c.eidx) : c.m1);
-  c.j = c.owner ? (c.c0 + c.tj) : ((c.ekind == 0) ? (c.c0 + c.eidx) : c.m1);
-  c.tabi = c.owner ? c.ti : ((c.ekind == 1) ? c.eidx : 16);
-  c.tabj = c.owner ? c.tj : ((c.ekind == 0) ? c.eidx : 16);
-  c.colnode = !c.owner && c.ekind == 1;
-  const int M = c.M, LD = c.LD, m1 = c.m1;
-  // ---- constant tables: entry e < 16 is the tile's own index, entry 16 is index M-1
-  if (c.tid < TB_N * 17) {
-    const int t = c.tid / 17, e = c.tid % 17;
-    const bool by_i = t <= TB_VN;
-    const int idx = e < 16 ? ((by_i ? c.r0 : c.c0) + e) : m1;
-    const size_t em = (size_t)m1 * LD + idx;
-    double x;
-    switch (t) {
-      case TB_DXL: x = a.DxL[idx]; break;
-      case TB_D2XL: x = a.D2xL[idx]; break;
-      case TB_LID: x = a.ulid[idx]; break;
-      case TB_WX: x = a.wx[idx]; break;
-      case TB_UN: x = a.UinT[em]; break;        // lid column, along the transposed copy
-      case TB_VN: x = a.VinT[em]; break;
-      case TB_DYL: x = a.DyL[idx]; break;
-      case TB_D2YL: x = a.D2yL[idx]; break;
-      case TB_WY: x = a.wy[idx]; break;
-      case TB_UE: x = a.Uin[em]; break;         // east-wall row
-      default: x = a.Vin[em]; break;
-    }
-    lds[TileLds::TAB + t * kTabStride + e] = x;
-  }
-  // ---- the node's state
-  c.u0 = c.v0 = c.p0 = c.px = c.py = 0.0;
-  const size_t ij = (size_t)c.i * LD + c.j, ijT = (size_t)c.j * LD + c.i;
-  if (c.owner || c.edge_thr) {
-    c.u0 = c.colnode ? a.U0T[ijT] : a.U0[ij];
-    c.v0 = c.colnode ? a.V0T[ijT] : a.V0[ij];
-    if (c.owner) c.p0 = a.P0[ij];
-  }
-  c.uc = c.u0; c.vc = c.v0;
-  // ---- job tiles: the CONSTANT rows of index M-1 (operators, boundary values of the state), once
-  if (c.anyE) {
-    double* erow = lds + TileLds::EROW + c.wv * kTileSlots * 64;
-    const int h = c.lane & 1, q = (c.lane >> 1) & 3, gi = (c.lane >> 3) & 3, sl = c.lane >> 5;
-    const size_t off = (size_t)m1 * LD + 16 * (c.kq + 4 * gi) + 4 * q + 2 * h;
-    const bool live = (c.kq + 4 * gi) < c.T;
-    const bool needA = c.rowE || c.cornE, needB = c.colE || c.cornE;
-    const double* row0 = c.role == 0 ? a.Dx : a.Uin;
-    const double* row1 = c.role == 0 ? a.D2x : a.Vin;
-    const double* row2 = c.role == 0 ? a.GxF : a.IxF;
-    const double* row3 = c.role == 0 ? a.UinT : a.Dy;
-    const double* row4 = c.role == 0 ? a.VinT : a.D2y;
-    if (live && needA) dma16<false>((sl ? row1 : row0) + off, erow);
-    if (live && (sl ? needB : needA)) dma16<false>((sl ? row3 : row2) + off, erow + 128);
-    if (live && needB && sl == 0) dma16<false>(row4 + off, erow + 256);
-  }
-  (void)M;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-}
-
-// GPV / LAST / DIAG as stage_body.  step0: state index this iteration started from (parity of the Z / P slabs).
-// stp: timing experiments (per-wave cycle stamps of this stage), or null
-template <bool GPV, bool LAST, int DIAG>
-__device__ __forceinline__ void tile_stage(TileCtx& c, const StageArgs a, double* lds, const int bx, const int step0,
-                                           const double dt, double* stp) {
-#ifdef LDC_TIMING
-#define LDC_PSTAMP(k) do { if (stp != nullptr && c.lane == 0) \
-    stp[((size_t)bx * kStageWaves + c.wv) * 8 + (k)] = (double)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define LDC_PSTAMP(k) do { (void)stp; (void)bx; } while (0)
-#endif
-  LDC_PSTAMP(0);
-  constexpr bool GP = GPV || (DIAG == 2);
-  static_assert(!(GPV && DIAG == 2), "stage 2 of SG carries no pressure contraction");
-  constexpr int VEL = LAST ? 1 : (DIAG == 1 ? 2 : 0);
-  constexpr int NA = GP ? 5 : 4;
-  constexpr int SA2 = (DIAG == 2) ? 6 : 2, SB2 = (DIAG == 2) ? 7 : 5;
-  double* red = lds;
-  const int tid = c.tid, lane = c.lane, wv = c.wv, role = c.role, kq = c.kq, ng = c.ng;
-  const int M = c.M, LD = c.LD, T = c.T, m1 = c.m1, NB = c.NB, I = c.I, J = c.J, r0 = c.r0, c0 = c.c0;
-  const bool rowE = c.rowE && (GP || VEL != 0), colE = c.colE && (GP || VEL != 0), cornE = c.cornE && (GP || VEL != 0);
-  const bool anyE = rowE || colE || cornE;
-  const bool owner = c.owner, edge_thr = c.edge_thr && (GP || VEL != 0);
-  const int ekind = c.ekind, eidx = c.eidx, i = c.i, j = c.j, ti = c.ti, tj = c.tj;
-  const double adt = a.alpha * dt;
-
-  RoleOps o;
-#ifdef LDC_TIMING
-  o.ablate = 0;
-#endif
-  o.role = role;
-  o.x4 = (DIAG == 2) ? (role == 0 ? 1 : 2) : 0;
-  if (role == 0) {
-    o.A0 = a.DxK; o.A1 = a.D2xK; o.B0 = a.UinTK; o.B1 = a.VinTK;
-    o.A2 = (DIAG == 2) ? a.DxK : a.GxFK; o.B2 = (DIAG == 2) ? a.WTK : a.T1TK;
-  } else {
-    o.A0 = a.UinK; o.A1 = a.VinK; o.B0 = a.DyK; o.B1 = a.D2yK;
-    o.A2 = (DIAG == 2) ? a.WK : a.IxFK; o.B2 = (DIAG == 2) ? a.DyK : a.T2TK;
-  }
-  auto gk = [&](int n) { return kq + 4 * n; };
-  double* erow = lds + TileLds::EROW + wv * kTileSlots * 64;
-
-  // ---- job tiles: the rows of index M-1 that CHANGE -- the pressure transforms (slot 5), omega (slots 6, 7)
-  if (anyE && (GPV || DIAG == 2)) {
-    const int h = lane & 1, q = (lane >> 1) & 3, gi = (lane >> 3) & 3, sl = lane >> 5;
-    const size_t off = (size_t)m1 * LD + 16 * (kq + 4 * gi) + 4 * q + 2 * h;
-    const bool live = (kq + 4 * gi) < T;
-    const bool needA = rowE || cornE, needB = colE || cornE;
-    if (GPV) {      // lanes 32..63 land in slot 5 (B2: T1T | T2T)
-      if (live && needB && sl == 1) dma16<true>((role == 0 ? a.T1T : a.T2T) + off, erow + 256);
-    } else {        // slot 6: omega row (role 1, A2); slot 7: omega^T row (role 0, B2)
-      if (live && sl == 0 && role == 1 && needA) dma16<true>(a.W + off, erow + 384);
-      if (live && sl == 1 && role == 0 && needB) dma16<true>(a.WT + off, erow + 384);
-    }
-  }
-  // omega on the row / column of index M-1 for the rank-1 completion of grad omega: one wave fetches, LDS serves
-  if (DIAG == 2 && c.tail && wv == 7 && lane < 34) {
-    const int e = lane % 17, which = lane / 17;
-    const int idx = e < 16 ? ((which == 0 ? c0 : r0) + e) : m1;
-    lds[TileLds::WEN + which * kTabStride + e] = gl_t<true>(which == 0 ? a.W : a.WT, (size_t)m1 * LD + idx);
-  }
-
-  // ---- fragments -----------------------------------------------------------------------------------
-  RoleFrags fa, fb;
-  ExtraFrags fx;
-  load_role<true>(fa, o, NB, I, J, ng > 0 ? gk(0) : 0, lane);
-  LDC_PSTAMP(1);
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the LDS-direct rows have landed (see stage_body)
-  v4d acc[NA];
-#pragma unroll
-  for (int q = 0; q < NA; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
-  EdgeAcc ea;
-#pragma unroll
-  for (int q = 0; q < 5; ++q) { ea.er[q] = 0.0; ea.ec[q] = 0.0; ea.ek[q] = 0.0; }
-  for (int n = 0; n < ng; n += 2) {
-    if (GP) load_extra<true>(fx, o, NB, I, J, gk(n), lane);
-    load_role<true>(fb, o, NB, I, J, gk(n + 1 < ng ? n + 1 : n), lane);
-    mfma_role<GP, NA>(fa, fx, acc, 0, o.x4);
-    if (anyE) edge_group<VEL, GP, SA2, SB2>(ea, fa, fx, o, erow, n, lane, rowE, colE, cornE);
-    if (n + 1 < ng) {
-      if (GP) load_extra<true>(fx, o, NB, I, J, gk(n + 1), lane);
-      load_role<true>(fa, o, NB, I, J, gk(n + 2 < ng ? n + 2 : n + 1), lane);
-      mfma_role<GP, NA>(fb, fx, acc, 0, o.x4);
-      if (anyE) edge_group<VEL, GP, SA2, SB2>(ea, fb, fx, o, erow, n + 1, lane, rowE, colE, cornE);
-    }
-  }
-
-  LDC_PSTAMP(2);
-  // ---- all partial results to LDS ---------------------------------------------------------------
-#pragma unroll
-  for (int q = 0; q < NA; ++q)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[((wv * NA + q) * 4 + r) * 64 + lane] = acc[q][r];
-  if (anyE) {
-    double* er = lds + TileLds::EDGE + wv * 15 * 16;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      if ((q == 0 && VEL == 0) || (q >= 1 && q < 4 && VEL != 1) || (q == 4 && !GP)) continue;
-      if (rowE) { const double x = quad_sum(ea.er[q]); if (lane < 16) er[q * 16 + lane] = x; }
-      if (colE) { const double y = quad_sum(ea.ec[q]); if (lane < 16) er[(5 + q) * 16 + lane] = y; }
-      if (cornE) { const double z = quad_sum(ea.ek[q]); if (lane < 16) er[(10 + q) * 16 + lane] = z; }
-    }
-  }
-  __syncthreads();
-  LDC_PSTAMP(3);
-
-  auto rsum = [&](int rl, int q) {
-    const int w = wv & 3;
-    double x = red[(((rl * 4 + 0) * NA + q) * 4 + w) * 64 + lane];
-    x += red[(((rl * 4 + 1) * NA + q) * 4 + w) * 64 + lane];
-    x += red[(((rl * 4 + 2) * NA + q) * 4 + w) * 64 + lane];
-    x += red[(((rl * 4 + 3) * NA + q) * 4 + w) * 64 + lane];
-    return x;
-  };
-  auto esum = [&](int rl, int kind, int q, int idx) {
-    const double* base = lds + TileLds::EDGE + (kind * 5 + q) * 16 + idx;
-    double x = base[(rl * 4 + 0) * 15 * 16];
-    x += base[(rl * 4 + 1) * 15 * 16];
-    x += base[(rl * 4 + 2) * 15 * 16];
-    x += base[(rl * 4 + 3) * 15 * 16];
-    return x;
-  };
-  const double* tab = lds + TileLds::TAB;
-
-  double sums[PS_NSUM] = {0, 0, 0, 0, 0, 0, 0, 0};
-  double maxs[2] = {0, 0};
-  double un = 0.0, vn = 0.0;
-  double dsum = 0.0;
-  double* tu = lds + TileLds::TILE;
-  double* tv = tu + 16 * 17;
-  double* tw = tv + 16 * 17;
-  double* tp = tw + 16 * 17;
-  const size_t ij = (size_t)i * LD + j;
-  const bool has_p = a.Pout != nullptr;
-
-  if (owner || edge_thr) {
-    const double uin = c.uc, vin = c.vc, u0 = c.u0, v0 = c.v0, p0 = c.p0;
-    double px = c.px, py = c.py;
-    const double wq = tab[TB_WX * kTabStride + c.tabi] * tab[TB_WY * kTabStride + c.tabj];
-    const double lidv = tab[TB_LID * kTabStride + c.tabi];
-    auto C = [&](int rl, int q) { return owner ? rsum(rl, q) : esum(rl, ekind, q, eidx); };
-    const bool valid = (i < M) && (j < M);
-    const bool interior = (i >= 1) && (i <= M - 2) && (j >= 1) && (j <= M - 2);
-    const bool full = owner || VEL == 1;
-    double ux = 0, vx = 0, uy = 0, vy = 0, lu = 0, lv = 0;
-    if (full) {
-      ux = C(0, 0); vx = C(0, 1); lu = C(0, 2) + C(1, 1); lv = C(0, 3) + C(1, 3);
-      uy = C(1, 0); vy = C(1, 2);
-    } else if (VEL == 2) {
-      vx = C(0, 0); uy = C(1, 0);
-    }
-    double dxl = 0, dyl = 0;
-    if (c.tail) {
-      dxl = tab[TB_DXL * kTabStride + c.tabi]; dyl = tab[TB_DYL * kTabStride + c.tabj];
-      const double d2xl = tab[TB_D2XL * kTabStride + c.tabi], d2yl = tab[TB_D2YL * kTabStride + c.tabj];
-      const double ue = tab[TB_UE * kTabStride + c.tabj], ve = tab[TB_VE * kTabStride + c.tabj];
-      const double un_ = tab[TB_UN * kTabStride + c.tabi], vn_ = tab[TB_VN * kTabStride + c.tabi];
-      nm_tail(ux, vx, uy, vy, lu, lv, dxl, d2xl, dyl, d2yl, ue, ve, un_, vn_);
-    }
-    if (GPV) {
-      px = valid ? C(0, 4) : 0.0;
-      py = valid ? C(1, 4) : 0.0;
-      c.px = px; c.py = py;
-    }
-    if (DIAG == 1) {
-      const double w = valid ? (vx - uy) : 0.0;
-      if (owner) tw[ti * 17 + tj] = w;
-      else { st_out(a.W + ij, w, c.wt); st_out(a.WT + (size_t)j * LD + i, w, c.wt); }
-      dsum = valid ? wq * w * w : 0.0;
-    }
-    if (DIAG == 2) {
-      double gx = C(0, 4), gy = C(1, 4);
-      if (c.tail) {
-        const double we = lds[TileLds::WEN + c.tabj], wn = lds[TileLds::WEN + kTabStride + c.tabi];
-        gx = nm_madd(dxl, we, gx); gy = nm_madd(wn, dyl, gy);
-      }
-      dsum = valid ? wq * nm_sq2(gx, gy) : 0.0;
-    }
-    const double Ru = nm_momentum(uin, vin, ux, uy, px, a.nu, lu);
-    const double Rv = nm_momentum(uin, vin, vx, vy, py, a.nu, lv);
-    const double Rp = nm_continuity(a.beta2, ux, vy);
-    if (owner) {
-      un = nm_madd(adt, Ru, u0); vn = nm_madd(adt, Rv, v0);
-      if (!valid) { un = 0.0; vn = 0.0; }
-      else if (j == M - 1) { un = lidv; vn = 0.0; }
-      else if (i == 0 || i == M - 1 || j == 0) { un = 0.0; vn = 0.0; }
-      if (has_p) {
-        const double pn = interior ? nm_madd(adt, Rp, p0) : 0.0;
-        st_out(a.Pout + ij, pn, c.wt);        // row-major: the transforms' rows of index M-1 contract whole rows of p
-        tp[ti * 17 + tj] = pn;
-        if (LAST) c.p0 = pn;
-      }
-      tu[ti * 17 + tj] = un;
-      tv[ti * 17 + tj] = vn;
-      c.uc = un; c.vc = vn;
-      if (LAST) {
-        const double du = un - u0, dv = vn - v0;
-        sums[PS_DU2] = valid ? du * du : 0.0;
-        sums[PS_DV2] = valid ? dv * dv : 0.0;
-        sums[PS_U02] = valid ? u0 * u0 : 0.0;
-        sums[PS_V02] = valid ? v0 * v0 : 0.0;
-        sums[PS_RU2] = valid ? Ru * Ru : 0.0;
-        sums[PS_RV2] = valid ? Rv * Rv : 0.0;
-        sums[PS_RP2] = interior ? Rp * Rp : 0.0;
-        sums[PS_E] = valid ? wq * nm_sq2(un, vn) : 0.0;
-        maxs[0] = fabs(un);
-        maxs[1] = fabs(vn);
-        c.u0 = un; c.v0 = vn;
-      }
-    } else if (LAST) {
-      sums[PS_U02] = u0 * u0; sums[PS_V02] = v0 * v0;
-      sums[PS_RU2] = Ru * Ru; sums[PS_RV2] = Rv * Rv;
-      sums[PS_E] = wq * nm_sq2(u0, v0);
-      maxs[0] = fabs(u0); maxs[1] = fabs(v0);
-    }
-  }
-  LDC_PSTAMP(4);
-  __syncthreads();
-  LDC_PSTAMP(5);
-  if (owner) {
-    // packed twins of this tile: what the other work-groups' fragments read (see stage_body)
-    const int hh = tid & 127, pl = hh >> 1, pr = pl & 15, pc = 4 * (pl >> 4) + 2 * (hh & 1);
-    const size_t kb = ((size_t)(I * NB + J) << 8) + 2 * hh, kbT = ((size_t)(J * NB + I) << 8) + 2 * hh;
-    const int e = pr * 17 + pc, eT = pc * 17 + pr;
-    if (tid < 128) {
-      st_out2(a.UoutK + kb, tu[e], tu[e + 1], c.wt); st_out2(a.UoutTK + kbT, tu[eT], tu[eT + 17], c.wt);
-      if (DIAG == 1) { st_out2(a.WK + kb, tw[e], tw[e + 1], c.wt); st_out2(a.WTK + kbT, tw[eT], tw[eT + 17], c.wt); }
-    } else {
-      st_out2(a.VoutK + kb, tv[e], tv[e + 1], c.wt); st_out2(a.VoutTK + kbT, tv[eT], tv[eT + 17], c.wt);
-      if (has_p) st_out2(a.PoutK + kb, tp[e], tp[e + 1], c.wt);
-    }
-  }
-  if (DIAG != 0) {
-    red[tid] = dsum;
-    __syncthreads();
-    if (wv == 0) {
-      double x = 0.0;
-#pragma unroll
-      for (int m = 0; m < kStageWaves; ++m) x += red[lane + 64 * m];
-      x = wave_sum(x);
-      double* slab = (DIAG == 1 ? a.partZ0 : a.partP0) + (size_t)((step0 > 0 ? step0 - 1 : 0) & 1) * a.stride;
-      if (lane == 0) st_out(slab + (size_t)bx * LDC_NPART, x, c.wt);
-    }
-  }
-  if (LAST) {
-#pragma unroll
-    for (int q = 0; q < PS_NSUM; ++q) red[q * kStageThreads + tid] = sums[q];
-    red[PS_UMAX * kStageThreads + tid] = maxs[0];
-    red[PS_VMAX * kStageThreads + tid] = maxs[1];
-    __syncthreads();
-    double* dst = a.partials + (size_t)bx * LDC_NPART;
-    {
-      double x = 0.0;
-#pragma unroll
-      for (int m = 0; m < kStageWaves; ++m) x += red[wv * kStageThreads + lane + 64 * m];
-      x = wave_sum(x);
-      if (lane == 0) st_out(dst + wv, x, c.wt);
-    }
-    if (wv < 2) {
-      double x = 0.0;
-#pragma unroll
-      for (int m = 0; m < kStageWaves; ++m) x = fmax(x, red[(PS_NSUM + wv) * kStageThreads + lane + 64 * m]);
-      x = wave_max(x);
-      if (lane == 0) st_out(dst + PS_NSUM + wv, x, c.wt);
-    }
-  }
-  LDC_PSTAMP(6);
-}
-
-// when the launch ends: the row-major forms of phi (and their transposed copies) from the resident registers
-__device__ __forceinline__ void tile_flush(const TileCtx& c, const StageArgs& a, double* lds) {
-  double* tu = lds + TileLds::TILE;
-  double* tv = tu + 16 * 17;
-  __syncthreads();
-  if (c.owner) {
-    const size_t ij = (size_t)c.i * c.LD + c.j;
-    a.Uout[ij] = c.u0; a.Vout[ij] = c.v0;
-    tu[c.ti * 17 + c.tj] = c.u0; tv[c.ti * 17 + c.tj] = c.v0;
-  }
-  __syncthreads();
-  if (c.owner) {
-    const int tr = c.tid >> 4, tc = c.tid & 15;
-    const size_t ot = (size_t)(c.c0 + tr) * c.LD + c.r0 + tc;
-    a.UoutT[ot] = tu[tc * 17 + tr];
-    a.VoutT[ot] = tv[tc * 17 + tr];
-  }
-}
-
-// One phase's argument block out of the kernel-argument segment, by value, AT the phase: read through a laundered
-// pointer so that the loads are neither hoisted out of the iteration loop nor all issued at kernel entry (four stage
-// blocks of ~80 pointers each held live across the loop cost ~440 SGPR and ~340 VGPR spills).
 typedef const __attribute__((address_space(4))) char* kernarg_ptr;
-template <typename T>
-__device__ __forceinline__ T phase_args(kernarg_ptr& base, size_t offset) {
-  asm volatile("" : "+s"(base));
-  T t;
-  __builtin_memcpy(&t, base + offset, sizeof(T));
-  return t;
-}
-#define LDC_TRIAL_ARG(T, member) phase_args<T>(kargs, __builtin_offsetof(TrialArgs, member))
 
-// SP: smoother mode (every stage differentiates its own stage pressure; FSG levels)   DIAGV: fused omega / Z / P
-template <bool SP, bool DIAGV>
-__global__ __launch_bounds__(kStageThreads, 2) void trial_kernel(const TrialArgs) {
-  static_assert(!(SP && DIAGV), "the smoother carries no diagnostics");
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  __shared__ TrialState S;
-  const int tid = threadIdx.x;
-  kernarg_ptr kargs = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();     // TrialArgs is the only argument
-  const int n_iters = LDC_TRIAL_ARG(int, n_iters);
-  unsigned* const sync = LDC_TRIAL_ARG(unsigned*, sync);
-  const bool local = LDC_TRIAL_ARG(int, local) != 0;
-  const int nblk = LDC_TRIAL_ARG(int, nt);
-  int bx = (int)blockIdx.x;
-  if (local) {
-    // One-XCD placement.  The launch holds several times more work-groups than tiles; the hardware deals them over
-    // the XCDs.  The first work-group to get here elects ITS XCD (it reads the id from the hardware, nothing is
-    // assumed about which block lands where); work-groups that find themselves on that XCD claim the tiles in the
-    // order they arrive, every other work-group leaves at once.  All T*T claimants then share one L2: the state they
-    // exchange needs no write-through and no trip over the fabric (plain stores; L1-bypassing loads served by the
-    // L2; the barrier counter an L2 atomic).  Should fewer than T*T work-groups of the elected XCD show up, the
-    // first barrier gives up after its bounded wait and the launch ends with LDC_E_SYNC like any other lost peer.
-    __shared__ int claim;
-    if (tid == 0) {
-      const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15u;   // HW_REG_XCC_ID, 4 bits
-      LDC_GLOBAL unsigned* w = (LDC_GLOBAL unsigned*)sync;
-      unsigned expect = 0u;
-      const bool won = __hip_atomic_compare_exchange_strong(w + LDC_SYNC_XCC, &expect, xcc + 1u, __ATOMIC_RELAXED,
-                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned elected = won ? xcc + 1u : expect;
-      int mine = -1;
-      if (elected == xcc + 1u) {
-        const unsigned k = __hip_atomic_fetch_add(w + LDC_SYNC_HEAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (k < (unsigned)nblk) mine = (int)k;
-      }
-      claim = mine;
-    }
-    __syncthreads();
-    bx = claim;
-    if (bx < 0) return;
-  }
-  // timing experiments: cycle stamps (s_memtime) of the LAST iteration's phase boundaries, thread 0 of every work-group
 #ifdef LDC_TIMING
-  double* const stamps = LDC_TRIAL_ARG(double*, stamps);
-#else
-  double* const stamps = nullptr;
+#include "ldc_trial_kernel.inc"      // round-2 persistent trial kernel: instrumented build only
 #endif
-#ifdef LDC_TIMING
-#define LDC_TSTAMP(k) do { if (stamps != nullptr && tid == 0 && it == n_iters - 1) \
-    stamps[(size_t)bx * 64 + (k)] = (double)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define LDC_TSTAMP(k) do { } while (0)
-#endif
-  {
-    const FinalArgs fa = LDC_TRIAL_ARG(FinalArgs, post.fin);
-    if (tid == 0) {
-      S.done = fa.ctrl[LDC_CTRL_DONE]; S.iter = fa.ctrl[LDC_CTRL_ITER]; S.step = fa.ctrl[LDC_CTRL_STEP];
-      S.flushed = fa.ctrl[LDC_CTRL_FLUSHED]; S.pdone = fa.ctrl[LDC_CTRL_PDONE]; S.drows = fa.ctrl[LDC_CTRL_DROWS];
-      S.dt = fa.scal[LDC_SCAL_DT]; S.umax = fa.scal[LDC_SCAL_UMAX]; S.vmax = fa.scal[LDC_SCAL_VMAX];
-      S.abort = 0;
-    }
-  }
-  TileCtx c;
-  c.wt = local ? 0 : 1;
-  tile_setup(c, LDC_TRIAL_ARG(StageArgs, st[0]), bx, lds);      // ends with a work-group barrier
-  unsigned phase = 0;
-  constexpr int D1 = DIAGV ? 1 : 0, D2 = DIAGV ? 2 : 0;
-  // the transforms of one pressure array as a phase (smoother mode: PA / PB / PA after stages 1-3; always: P)
-  auto transforms = [&](int which) {
-    const PostArgs pq = LDC_TRIAL_ARG(PostArgs, post);
-    const double* P = which < 0 ? pq.P : LDC_TRIAL_ARG(const double*, Pst[which < 0 ? 0 : which]);
-    const double* PK = which < 0 ? pq.PK : LDC_TRIAL_ARG(const double*, PstK[which < 0 ? 0 : which]);
-    post_phase(pq, P, PK, bx, nblk, lds, tid, local ? 0 : 1);
-  };
-  // A phase's argument block is fetched BEFORE the barrier that precedes the phase: the scalar loads are in flight
-  // while the work-group waits for its peers instead of in front of the first fragment loads.
-  StageArgs a_next = LDC_TRIAL_ARG(StageArgs, st[0]);
-  for (int it = 0; it < n_iters; ++it) {
-    if (S.done != 0) break;                      // every work-group holds the same latch
-    const int step0 = S.step;
-    const double dt = S.dt;
-    double* const stq = (stamps != nullptr && it == n_iters - 1) ? stamps + (size_t)nblk * 64 : nullptr;
-    LDC_TSTAMP(0);
-    tile_stage<true, false, D1>(c, a_next, lds, bx, step0, dt, stq);
-    LDC_TSTAMP(1);
-    a_next = LDC_TRIAL_ARG(StageArgs, st[1]);
-    if (!grid_sync(sync, phase, nblk, tid, &S, local)) return;
-    LDC_TSTAMP(2);
-    if (SP) {
-      transforms(0);
-      if (!grid_sync(sync, phase, nblk, tid, &S, local)) return;
-    }
-    tile_stage<SP, false, D2>(c, a_next, lds, bx, step0, dt, stq ? stq + (size_t)nblk * 64 : nullptr);
-    if (DIAGV && tid == 0) { S.pdone = step0; S.drows = nblk; }     // Z and P partials of state `step0` are complete
-    LDC_TSTAMP(3);
-    a_next = LDC_TRIAL_ARG(StageArgs, st[2]);
-    if (!grid_sync(sync, phase, nblk, tid, &S, local)) return;
-    LDC_TSTAMP(4);
-    if (SP) {
-      transforms(1);
-      if (!grid_sync(sync, phase, nblk, tid, &S, local)) return;
-    }
-    tile_stage<SP, false, 0>(c, a_next, lds, bx, step0, dt, stq ? stq + (size_t)nblk * 128 : nullptr);
-    LDC_TSTAMP(5);
-    a_next = LDC_TRIAL_ARG(StageArgs, st[3]);
-    if (!grid_sync(sync, phase, nblk, tid, &S, local)) return;
-    LDC_TSTAMP(6);
-    if (SP) {
-      transforms(2);
-      if (!grid_sync(sync, phase, nblk, tid, &S, local)) return;
-    }
-    tile_stage<SP, true, 0>(c, a_next, lds, bx, step0, dt, stq ? stq + (size_t)nblk * 192 : nullptr);
-    if (tid == 0) S.step = step0 + 1;            // one more state update done
-    LDC_TSTAMP(7);
-    if (!grid_sync(sync, phase, nblk, tid, &S, local)) return;
-    LDC_TSTAMP(8);
-    fin_work<true>(LDC_TRIAL_ARG(FinalArgs, post.fin), lds, tid, &S, bx == 0);
-    LDC_TSTAMP(9);
-    transforms(-1);
-    LDC_TSTAMP(10);
-    a_next = LDC_TRIAL_ARG(StageArgs, st[0]);
-    if (it + 1 < n_iters && !grid_sync(sync, phase, nblk, tid, &S, local)) return;
-  }
-  tile_flush(c, LDC_TRIAL_ARG(StageArgs, st[3]), lds);
-  if (bx == 0 && tid == 0) {
-    const FinalArgs fa = LDC_TRIAL_ARG(FinalArgs, post.fin);
-    fa.ctrl[LDC_CTRL_DONE] = S.done; fa.ctrl[LDC_CTRL_ITER] = S.iter; fa.ctrl[LDC_CTRL_STEP] = S.step;
-    fa.ctrl[LDC_CTRL_FLUSHED] = S.flushed; fa.ctrl[LDC_CTRL_PDONE] = S.pdone; fa.ctrl[LDC_CTRL_DROWS] = S.drows;
-    fa.ctrl[LDC_CTRL_LIVE] = 0;                  // every iteration of this launch has been closed in it
-    fa.scal[LDC_SCAL_DT] = S.dt; fa.scal[LDC_SCAL_UMAX] = S.umax; fa.scal[LDC_SCAL_VMAX] = S.vmax;
-  }
-}
 
 // ---------------------------------------------------------------------------------------
 // small-N trial kernel: a trial's T x T work-groups on ONE XCD, contraction families per wave, resident operators
@@ -2622,7 +1930,8 @@ int launch_closing_diagnostics(ldc_solver* s, hipStream_t st) {
   return launch_finalize(s, 1, 0, st);
 }
 
-// ---- persistent trial kernel ------------------------------------------------------------------------------
+#ifdef LDC_TIMING
+// ---- round-2 persistent trial kernel (instrumented build only) ------------------------------------------------------------------------------
 constexpr size_t kTrialLdsBytes = TileLds::BYTES;
 static_assert(kTrialLdsBytes <= kLdsLimit, "trial kernel LDS");
 static_assert(kTrialLdsBytes >= sizeof(double) * kThreads * (PS_N + 2), "finalize scratch fits");
@@ -2639,9 +1948,16 @@ int enable_trial_lds() {
   return 0;
 }
 
+#endif
+
 // every work-group of a trial must be resident at once (one per CU: the LDS carve allows no second one)
 bool persistent_available(const ldc_solver* s) {
+#ifdef LDC_TIMING
   return s->p.sync != nullptr && s->nt <= s->n_cus && s->ablate == 0;
+#else
+  (void)s;
+  return false;               // modes 1 and 2 exist in the instrumented build only (ldc_trial_kernel.inc)
+#endif
 }
 // one-XCD placement: every tile's work-group on the same XCD (one per CU)
 bool local_available(const ldc_solver* s) {
@@ -2759,6 +2075,7 @@ int launch_xcd(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
   return xcd_launch_any(xl, s->p.stage_pressure != 0, with_diag != 0, T, s->n_xcds, st);
 }
 
+#ifdef LDC_TIMING
 TrialArgs make_trial_args(const ldc_solver* s, int n_iters, int with_diag) {
   TrialArgs ta;
   memset(&ta, 0, sizeof(ta));
@@ -2795,6 +2112,9 @@ int launch_trial(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
   else hipLaunchKernelGGL((trial_kernel<false, false>), grid, block, kTrialLdsBytes, st, ta);
   return (int)hipGetLastError();
 }
+#else
+int launch_trial(ldc_solver*, int, int, hipStream_t) { return LDC_E_STATE; }      // unreachable: persistent_available() is false
+#endif
 
 // Captures record kernel launches on a private non-blocking stream and nothing else, so no call anywhere needs to be
 // prohibited while one runs: relaxed mode.  (In the stricter modes HIP refuses, for instance, a synchronous copy in
@@ -2854,9 +2174,11 @@ int ensure_kernel_attributes() {
   if (dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
   if (g_attrs_done[dev]) return 0;
   int e;
-  if ((e = enable_stage_lds_all<false>()) != 0 || (e = enable_stage_lds_all<true>()) != 0 || (e = enable_trial_lds()) != 0 ||
-      (e = enable_xcd_lds()) != 0)
+  if ((e = enable_stage_lds_all<false>()) != 0 || (e = enable_stage_lds_all<true>()) != 0 || (e = enable_xcd_lds()) != 0)
     return e;
+#ifdef LDC_TIMING
+  if ((e = enable_trial_lds()) != 0) return e;
+#endif
   g_attrs_done[dev] = true;
   return 0;
 }
@@ -3075,7 +2397,7 @@ int ldc_solver_set_graph_iters(ldc_solver* s, int n) {
 int ldc_solver_set_persistent(ldc_solver* s, int mode) {
   if (!s) return LDC_E_STATE;
   if (mode < -1 || mode > 3) return LDC_E_ARG;
-  if ((mode == 1 || mode == 2) && (s->p.sync == nullptr || s->nt > s->n_cus)) return LDC_E_ARG;
+  if ((mode == 1 || mode == 2) && !persistent_available(s)) return LDC_E_ARG;     // (always, in the product build)
   s->persist_mode = mode;
   if (mode == 2 && !local_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }
   if (mode == 3 && !xcd_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }

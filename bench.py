@@ -318,7 +318,7 @@ def main():
     ap.add_argument("--Re", type=float, default=WORKLOAD["Re"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-farm", action="store_true", help="skip the batched-trials (sweep-shaped) measurement")
-    ap.add_argument("--persistent", type=int, default=-1, help="-1 auto, 0 launch per stage, 1 persistent kernel")
+    ap.add_argument("--persistent", type=int, default=-1, help="-1 auto, 0 launch per stage, 3 small-N trial kernel (N <= 79)")
     a = ap.parse_args()
 
     import torch
@@ -347,8 +347,8 @@ def main():
     s = make_solver(a.N, a.Re, f"cuda:{local}", graph_iters=gi, persistent=a.persistent)
     s._begin(0.0)
     from solvers.spectral import ldc_lib as L
-    persistent = (a.persistent == 1) or (a.persistent == -1 and s.T * s.T <= L.PERSIST_AUTO_TILES)
-    launch_path = "persistent" if persistent else ("graph" if a.steps % gi == 0 else "graph+eager")
+    mode = int(L.lib().ldc_solver_mode(s._handle))         # what the library resolved: 0 launch per stage, 3 small-N kernel
+    launch_path = "persistent" if mode != 0 else ("graph" if a.steps % gi == 0 else "graph+eager")
     # warm-up (also instantiates both hipGraphs): W untimed steps, at least two full captures
     timed_iterations(s, max(a.warmup, 2 * gi), True, barrier)
     timed_iterations(s, 2 * gi, False, barrier)

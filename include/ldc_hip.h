@@ -195,18 +195,13 @@ int ldc_prime(ldc_solver *s, void *stream);
 int ldc_solver_enqueue(ldc_solver *s, int n_iters, int with_diagnostics, void *stream);
 /* iterations captured per graph (default 64); must be set before the first enqueue      */
 int ldc_solver_set_graph_iters(ldc_solver *s, int iters_per_graph);
-/* How ldc_solver_enqueue runs the loop.  mode 0: one launch per RK stage (hipGraph replay); 1: the persistent   */
-/* trial kernel -- ALL n_iters iterations in ONE launch of T*T work-groups that keep their tile and meet at a    */
-/* counter barrier per stage (needs desc->sync and T*T <= CUs of the device, else LDC_E_ARG); 2: the same kernel  */
-/* with all T*T work-groups on ONE XCD (T*T <= LDC_PERSIST_XCD_TILES): the launch is 8x over-subscribed, the      */
-/* first work-group to arrive elects its XCD (HW_REG_XCC_ID), work-groups of that XCD claim the tiles, the rest   */
-/* leave at once; state then crosses work-groups through that XCD's L2 (plain stores, L1-bypassing loads, L2      */
-/* atomics) instead of write-through stores and the fabric; -1 (default): mode 2 when it is available and         */
-/* T*T <= LDC_PERSIST_AUTO_XCD_TILES, else mode 1 when T*T <= LDC_PERSIST_AUTO_TILES, else mode 0.  Same          */
-/* arithmetic in every mode: records and fields are bit-identical.  The persistent kernel reads the boundary      */
-/* values of index M-1 (tail layout) once, from U / UT / V / VT: they must equal those of the stage buffers       */
-/* UA.. / UB.. (they do after the first iteration that follows an upload; a call with n_iters == 1 always runs    */
-/* launch by launch).                                                                                             */
+/* How ldc_solver_enqueue runs the loop.  mode 0: one launch per RK stage (hipGraph replay).                       */
+/* modes 1 and 2: the round-2 persistent trial kernel (csrc/ldc_trial_kernel.inc: T*T work-groups that keep their   */
+/* tile and meet at a counter barrier per stage; 2 = all of them on one XCD).  INSTRUMENTED BUILD ONLY               */
+/* (ldc_timing_build() == 1): it lost to mode 0 at every size and to mode 3 where a persistent kernel pays, so the   */
+/* product library does not carry it and answers LDC_E_ARG; there it needs desc->sync, T*T <= CUs (mode 2:           */
+/* T*T <= LDC_PERSIST_XCD_TILES) and gives records bit-identical to mode 0.                                          */
+/* -1 (default): mode 3 where it applies and ceil(M/16)^2 <= LDC_XCD_AUTO_TILES, else mode 0.                         */
 /* mode 3: the small-N trial kernel (csrc/ldc_xcd_kernel.inc) -- ALL n_iters iterations in one launch, the trial's     */
 /* ceil(M/16)^2 work-groups on ONE XCD elected at run time, one contraction family per wave over the full contraction   */
 /* index, the operator fragments resident in registers, state exchanged through that XCD's L2, the pressure path and    */

@@ -2,6 +2,8 @@
 and with the persistent trial kernel, anywhere (1) and on one XCD (2) -- development aid.
     python tools/ab_fsg_persist.py"""
 import os, sys, time
+# modes 1 and 2 live in the instrumented build only (csrc/ldc_trial_kernel.inc, -DLDC_TIMING)
+os.environ.setdefault("LDC_HIP_LIB", os.path.join(os.getcwd(), "02689-advancednumericalalgorithmp3_amd", "lib", "libldc_hip_timing.so"))
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "02689-advancednumericalalgorithmp3_amd", "src"))
 import torch
 from solvers.spectral.fsg import FSGSolver

@@ -2,6 +2,8 @@
     python tools/ab_persist.py [N ...]        env: AB_DIAG=0/1 (default 1), AB_ITERS"""
 import os
 import sys
+# modes 1 and 2 live in the instrumented build only (csrc/ldc_trial_kernel.inc, -DLDC_TIMING)
+os.environ.setdefault("LDC_HIP_LIB", os.path.join(os.getcwd(), "02689-advancednumericalalgorithmp3_amd", "lib", "libldc_hip_timing.so"))
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "02689-advancednumericalalgorithmp3_amd", "src"))
 import torch
 from solvers.spectral import ldc_lib as L

@@ -1,5 +1,7 @@
 """Where does the persistent path first differ from the launch path? (development aid)"""
 import os, sys
+# modes 1 and 2 live in the instrumented build only (csrc/ldc_trial_kernel.inc, -DLDC_TIMING)
+os.environ.setdefault("LDC_HIP_LIB", os.path.join(os.getcwd(), "02689-advancednumericalalgorithmp3_amd", "lib", "libldc_hip_timing.so"))
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "02689-advancednumericalalgorithmp3_amd", "src"))
 import numpy as np
 from solvers.spectral.sg import SGSolver
