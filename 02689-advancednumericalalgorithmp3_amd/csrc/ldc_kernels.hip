@@ -1412,6 +1412,11 @@ typedef const __attribute__((address_space(4))) char* kernarg_ptr;
 #include "ldc_xcd_kernel.inc"
 
 // ---------------------------------------------------------------------------------------
+// trial-per-CU kernel: one work-group = one trial, the stage state in LDS, a launch carries a batch
+// ---------------------------------------------------------------------------------------
+#include "ldc_cu_kernel.inc"
+
+// ---------------------------------------------------------------------------------------
 // palinstrophy kernel:  P = 1/2 sum W ((Dx w)^2 + (w Dy^T)^2)
 // ---------------------------------------------------------------------------------------
 struct PalinArgs {
@@ -1698,6 +1703,7 @@ struct ldc_batch {
   PostArgs* d_postP;         // stand-alone transforms of P (ungated): what follows a launch of the small-N trial kernel
   XArgs* d_xargs[2];         // [with_diagnostics] argument blocks of the small-N trial kernel
   unsigned* d_xsync;         // XG_LEN launch words, then XS_LEN counter words per trial (zeroed before every launch)
+  CArgs* d_cargs[2];         // [with_diagnostics] argument blocks of the trial-per-CU kernel
   int post_grid[2], postT_grid, post_close_grid, postP_grid;
   int iters_per_graph;
   hipGraphExec_t graph[2];
@@ -1964,10 +1970,13 @@ bool local_available(const ldc_solver* s) {
   return persistent_available(s) && s->nt <= LDC_PERSIST_XCD_TILES && s->nt + 4 <= s->n_cus / s->n_xcds;
 }
 bool xcd_available(const ldc_solver* s);
+bool cu_available(const ldc_solver* s);
 int xcd_tiles(const ldc_solver* s);
 // 0: launch per stage   1: persistent trial kernel   2: persistent, one-XCD placement   3: small-N trial kernel
+// 4: trial-per-CU kernel
 int persistent_mode(const ldc_solver* s) {
   if (s->persist_mode == 0) return 0;
+  if (s->persist_mode == 4) return cu_available(s) ? 4 : 0;
   if (s->persist_mode == 3) return xcd_available(s) ? 3 : 0;
   if (s->persist_mode == -1 && xcd_available(s) && xcd_tiles(s) * xcd_tiles(s) <= LDC_XCD_AUTO_TILES) return 3;
   if (!persistent_available(s)) return 0;
@@ -2075,6 +2084,76 @@ int launch_xcd(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
   return xcd_launch_any(xl, s->p.stage_pressure != 0, with_diag != 0, T, s->n_xcds, st);
 }
 
+// ---- trial-per-CU kernel (mode 4) ------------------------------------------------------------------------------
+constexpr size_t kCuLdsMax = kLdsLimit - 1024;       // (the kernel also has a few static words of LDS)
+template <int T>
+int enable_cu_lds_t() {
+  const void* k[3] = {reinterpret_cast<const void*>(cu_kernel<T, false, false>), reinterpret_cast<const void*>(cu_kernel<T, false, true>),
+                      reinterpret_cast<const void*>(cu_kernel<T, true, false>)};
+  for (const void* f : k) {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCuLdsMax);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+int enable_cu_lds() {
+  int e;
+  if ((e = enable_cu_lds_t<1>()) != 0 || (e = enable_cu_lds_t<2>()) != 0 || (e = enable_cu_lds_t<3>()) != 0) return e;
+  return 0;
+}
+// the stage state of the trial, in both orientations, and the four operators fit one CU's LDS
+bool cu_available(const ldc_solver* s) {
+  const int M = s->p.M, T = (M + 15) / 16;
+  return M >= 3 && M <= kCMaxM && T <= kCT && s->p.LD / 16 >= T && cu_lds_bytes(M) <= kCuLdsMax &&
+         s->p.partials_stride >= (int64_t)LDC_NPART;
+}
+bool use_cu(const ldc_solver* s) { return persistent_mode(s) == 4; }
+
+CArgs make_cargs(const ldc_solver* s, int with_diag) {
+  const ldc_problem& p = s->p;
+  CArgs a;
+  memset(&a, 0, sizeof(a));
+  a.M = p.M; a.LD = p.LD; a.NB = p.LD / 16;
+  a.with_diag = with_diag;
+  a.nu = p.nu; a.beta2 = p.beta2;
+  a.Dx = p.Dx; a.D2x = p.D2x; a.Dy = p.Dy; a.D2y = p.D2y;
+  a.GxF = p.GxF; a.GyF = p.GyF; a.IxF = p.IxF; a.IyF = p.IyF;
+  a.ulid = p.ulid; a.wx = p.wx; a.wy = p.wy;
+  a.U = p.U; a.UT = p.UT; a.V = p.V; a.VT = p.VT; a.P = p.P;
+  a.UK = p.UK; a.UTK = p.UTK; a.VK = p.VK; a.VTK = p.VTK; a.PK = p.PK;
+  a.partZ0 = p.partials + p.partials_stride; a.partP0 = p.partials + 3 * p.partials_stride;
+  a.stride = p.partials_stride;
+  a.fin = make_final_args(s, with_diag, 1);
+  return a;
+}
+
+template <int T>
+int cu_launch_t(const CLaunch& cl, bool sp, bool diag, size_t lds_bytes, hipStream_t st) {
+  const dim3 grid(cl.B), block(64 * T * T);
+  if (sp) hipLaunchKernelGGL((cu_kernel<T, true, false>), grid, block, lds_bytes, st, cl);
+  else if (diag) hipLaunchKernelGGL((cu_kernel<T, false, true>), grid, block, lds_bytes, st, cl);
+  else hipLaunchKernelGGL((cu_kernel<T, false, false>), grid, block, lds_bytes, st, cl);
+  return (int)hipGetLastError();
+}
+int cu_launch_any(const CLaunch& cl, const ldc_solver* s0, int with_diag, hipStream_t st) {
+  const int M = s0->p.M, T = (M + 15) / 16;
+  const bool sp = s0->p.stage_pressure != 0, diag = with_diag != 0;
+  const size_t bytes = cu_lds_bytes(M);
+  switch (T) {
+    case 1: return cu_launch_t<1>(cl, sp, diag, bytes, st);
+    case 2: return cu_launch_t<2>(cl, sp, diag, bytes, st);
+    case 3: return cu_launch_t<3>(cl, sp, diag, bytes, st);
+    default: return LDC_E_ARG;
+  }
+}
+int launch_cu(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
+  CLaunch cl;
+  memset(&cl, 0, sizeof(cl));
+  cl.B = 1; cl.n_iters = n_iters; cl.trials = nullptr;
+  cl.one = make_cargs(s, with_diag);
+  return cu_launch_any(cl, s, with_diag, st);
+}
+
 #ifdef LDC_TIMING
 TrialArgs make_trial_args(const ldc_solver* s, int n_iters, int with_diag) {
   TrialArgs ta;
@@ -2174,7 +2253,8 @@ int ensure_kernel_attributes() {
   if (dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
   if (g_attrs_done[dev]) return 0;
   int e;
-  if ((e = enable_stage_lds_all<false>()) != 0 || (e = enable_stage_lds_all<true>()) != 0 || (e = enable_xcd_lds()) != 0)
+  if ((e = enable_stage_lds_all<false>()) != 0 || (e = enable_stage_lds_all<true>()) != 0 || (e = enable_xcd_lds()) != 0 ||
+      (e = enable_cu_lds()) != 0)
     return e;
 #ifdef LDC_TIMING
   if ((e = enable_trial_lds()) != 0) return e;
@@ -2236,7 +2316,8 @@ int build_graph(ldc_solver* s, int with_diag) {
 size_t batch_bytes(int B) {
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
   return 4 * up(sizeof(StageArgs) * B) + 6 * up(sizeof(PostArgs) * B) + up(sizeof(PalinArgs) * B) +
-         up(sizeof(FinalArgs) * B) + 2 * up(sizeof(XArgs) * B) + up(sizeof(uint32_t) * (XG_LEN + (size_t)XS_LEN * B));
+         up(sizeof(FinalArgs) * B) + 2 * up(sizeof(XArgs) * B) + up(sizeof(uint32_t) * (XG_LEN + (size_t)XS_LEN * B)) +
+         2 * up(sizeof(CArgs) * B);
 }
 
 int batch_launch_stage(ldc_batch* b, int k, int diag, hipStream_t st) {
@@ -2396,11 +2477,12 @@ int ldc_solver_set_graph_iters(ldc_solver* s, int n) {
 
 int ldc_solver_set_persistent(ldc_solver* s, int mode) {
   if (!s) return LDC_E_STATE;
-  if (mode < -1 || mode > 3) return LDC_E_ARG;
+  if (mode < -1 || mode > 4) return LDC_E_ARG;
   if ((mode == 1 || mode == 2) && !persistent_available(s)) return LDC_E_ARG;     // (always, in the product build)
   s->persist_mode = mode;
   if (mode == 2 && !local_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }
   if (mode == 3 && !xcd_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }
+  if (mode == 4 && !cu_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }
   return 0;
 }
 
@@ -2520,6 +2602,12 @@ int ldc_solver_enqueue(ldc_solver* s, int n_iters, int with_diag, void* stream) 
     if ((e = launch_post(s, s->p.P, 0, 0, 0, st)) != 0) return e;
     return with_diag ? launch_closing_diagnostics(s, st) : 0;
   }
+  if (n_iters > 1 && use_cu(s)) {
+    int e = launch_cu(s, n_iters, with_diag, st);
+    if (e) return e;
+    if ((e = launch_post(s, s->p.P, 0, 0, 0, st)) != 0) return e;
+    return with_diag ? launch_closing_diagnostics(s, st) : 0;
+  }
   if (n_iters > 1 && use_persistent(s)) {
     const int e = launch_trial(s, n_iters, with_diag, st);
     if (e) return e;
@@ -2628,6 +2716,12 @@ int ldc_batch_create(ldc_solver* const* solvers, int n_trials, void* workspace, 
       b->d_xargs[wd] = reinterpret_cast<XArgs*>(wd == 0 ? xa0 : xa1);
       put(b->d_xargs[wd], hx.data(), sizeof(XArgs) * n_trials);
     }
+    for (int wd = 0; wd < 2; ++wd) {
+      std::vector<CArgs> hc(n_trials);
+      for (int q = 0; q < n_trials; ++q) hc[q] = make_cargs(solvers[q], wd);
+      b->d_cargs[wd] = reinterpret_cast<CArgs*>(carve(sizeof(CArgs) * n_trials));
+      put(b->d_cargs[wd], hc.data(), sizeof(CArgs) * n_trials);
+    }
   }
   if (he != hipSuccess) { delete b; return (int)he; }
   *out = b;
@@ -2644,12 +2738,42 @@ int ldc_batch_destroy(ldc_batch* b) {
   return 0;
 }
 
+// Which kernel advances a batch of small trials.  The small-N kernel gives every trial an XCD: 8 (at T'^2 <= 16: up to
+// 8 x floor(32 / T'^2)) trials advance at once, the rest wait; the trial-per-CU kernel advances all of them at once, each
+// several times slower.  Asked for explicitly (mode 4 on every trial) it is taken whenever it applies; in auto mode from
+// LDC_CU_AUTO_TRIALS trials on.
+bool batch_uses_cu(const ldc_batch* b) {
+  bool all_avail = true, all_asked = true, all_auto = true;
+  for (const ldc_solver* t : b->s) {
+    all_avail = all_avail && cu_available(t);
+    all_asked = all_asked && t->persist_mode == 4;
+    all_auto = all_auto && t->persist_mode == -1;
+  }
+  if (!all_avail) return false;
+  if (all_asked) return true;
+  return all_auto && b->B >= LDC_CU_AUTO_TRIALS;
+}
+
 int ldc_batch_enqueue(ldc_batch* b, int n_iters, int with_diag, void* stream) {
   if (!b) return LDC_E_STATE;
   if (n_iters < 0) return LDC_E_ARG;
   { const int e = on_own_device(b->s[0]); if (e) return e; }
   with_diag = with_diag ? 1 : 0;
   hipStream_t st = as_stream(stream);
+  if (n_iters > 1 && batch_uses_cu(b)) {
+    // trial-per-CU kernel: one work-group per trial, the whole batch in one launch, then the transforms of the final
+    // pressures in the launch path's form
+    const ldc_solver* s0 = b->s[0];
+    CLaunch cl;
+    memset(&cl, 0, sizeof(cl));
+    cl.B = b->B; cl.n_iters = n_iters; cl.trials = b->d_cargs[with_diag];
+    { const int e = cu_launch_any(cl, s0, with_diag, st); if (e) return e; }
+    const PostArgs pdummy = {};
+    hipLaunchKernelGGL(post_kernel<true>, dim3(b->postP_grid, b->B), dim3(kThreads), 0, st, pdummy,
+                       (const PostArgs*)b->d_postP);
+    { const int e = (int)hipGetLastError(); if (e) return e; }
+    return with_diag ? batch_closing_diagnostics(b, st) : 0;
+  }
   {
     // small-N trial kernel: every trial of the batch on an XCD of its own (as many trials per launch as the XCDs hold,
     // the rest in further launches), then the transforms of the final pressures in the launch path's form

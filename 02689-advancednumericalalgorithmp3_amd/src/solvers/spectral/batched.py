@@ -132,7 +132,7 @@ class BatchedSGSolver:
         import torch
         dev = self.solvers[0].device
         starts = [int(s.d["ctrl"].cpu().numpy()[L.CTRL_ITER]) for s in self.solvers]
-        resident = int(n_iters) > 1 and all(L.lib().ldc_solver_mode(s._handle) == 3 for s in self.solvers)
+        resident = int(n_iters) > 1 and all(L.lib().ldc_solver_mode(s._handle) in (3, 4) for s in self.solvers)
         lock = L.resident_lock(dev.index or 0) if resident else contextlib.nullcontext()
         with lock, torch.cuda.device(dev):        # (see ldc_lib.resident_lock: co-resident launches one at a time per device)
             L.check(L.lib().ldc_batch_enqueue(self._batch, int(n_iters), int(bool(diagnostics)), L.stream_ptr(dev)),

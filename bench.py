@@ -32,6 +32,8 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE J
               many regions there were, `launch_path` what the K iterations were enqueued as ("graph": hipGraph
               replays of captures of at most 64 iterations that divide K, "graph+eager" when K has a remainder,
               "persistent": one launch of the persistent trial kernel).
+* small_n   : BASELINE.json configs[1] (N=64, Re=400) on the same GPU: full iterations per second through the small-N
+              trial kernel (what the solver picks by default at N <= 79) and through the launch path (N = 1 only).
 * farm      : a second, sweep-shaped measurement for the multi-GPU runs -- every rank advances `trials_per_gpu`
               equal-N trials the way main.py advances the trials a rank owns in the Hydra multirun / Optuna search:
               two batches with shared launches, side by side on two HIP streams of different priority;
@@ -309,6 +311,41 @@ def ghia_block(N, Re):
                     "(its trajectory is reproduced to 1e-12); the converged figures are the meaningful ones"}
 
 
+def small_n_block(device, N=64, Re=400.0, K=4096):
+    """BASELINE.json configs[1] (solver=spectral N=64 Re=400 on one MI355X) beside the headline: full solve() iterations per
+    second as the solver runs that size by default -- the small-N trial kernel (csrc/ldc_xcd_kernel.inc: all iterations of a
+    chunk in one launch, the trial's 5 x 5 work-groups on one XCD) -- and on the launch path (persistent=0) for comparison.
+    Median of five regions of K iterations each, HIP events on the launch stream."""
+    import torch
+    from solvers.spectral import ldc_lib as L
+    out = {"workload": f"solver=spectral (SG) N={N} Re={Re:g} fp64, full solve() iteration, fluid from rest", "steps": K}
+    for name, mode in (("value", -1), ("launch_path_value", 0)):
+        s = make_solver(N, Re, device, graph_iters=64, persistent=mode)
+        s._begin(0.0)
+        resolved = int(L.lib().ldc_solver_mode(s._handle))
+        t = []
+        for _ in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            L.check(L.lib().ldc_solver_enqueue(s._handle, K, 1, L.stream_ptr()), "enqueue")
+            e1.record()
+            torch.cuda.synchronize()
+            t.append(e0.elapsed_time(e1) * 1e-3)
+        assert L.lib().ldc_solver_status(s._handle) == 0, "small-N trial kernel gave up a wait (LDC_E_SYNC)"
+        rec = s.d["rec"].cpu().numpy()
+        assert bool((rec == rec).all()), "non-finite history record at N=64"
+        s.close()
+        t = sorted(t[1:])
+        out[name] = K / t[len(t) // 2]
+        if mode == -1:
+            out["mode"] = resolved
+            out["us_per_step"] = 1e6 * t[len(t) // 2] / K
+    out["unit"] = "steps/s"
+    return out
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -411,6 +448,7 @@ def main():
                          "iteration_flops": flops_per_step(a.N, True)},
         }
         out["farm"] = farm
+        out["small_n"] = small_n_block(f"cuda:{local}") if world == 1 else None
         mfma = pmc_mfma_util(a.N, t_stage)
         if mfma is not None:
             out["roofline"].update(mfma)

@@ -215,8 +215,17 @@ int ldc_solver_set_graph_iters(ldc_solver *s, int iters_per_graph);
 #define LDC_PERSIST_AUTO_XCD_TILES 0
 #define LDC_XCD_TILES 25
 #define LDC_XCD_AUTO_TILES 25      /* measured faster than the launch path at every size it applies to (profiles/r03_xcd_ab.log) */
+/* mode 4: the trial-per-CU kernel (csrc/ldc_cu_kernel.inc) -- ONE work-group advances the trial: the stage state and the  */
+/* operators live in the CU's LDS, one wave per 16 x 16 tile runs all contractions of its tile, no hand-over between        */
+/* work-groups at all.  Needs M <= LDC_CU_MAX_M (the LDS), else LDC_E_ARG.  For one trial it is slower than mode 3 (one CU   */
+/* instead of up to 25); its place is the BATCH: ldc_batch_enqueue advances all trials of a batch at once with it, one CU   */
+/* each (256 at a time), when every trial asked for mode 4, or in mode -1 from LDC_CU_AUTO_TRIALS trials on.  Same entry     */
+/* and exit state as mode 3 (row-major phi^n in, row-major and packed forms out); trajectories agree with the other paths   */
+/* to rounding.                                                                                                             */
+#define LDC_CU_MAX_M 44
+#define LDC_CU_AUTO_TRIALS 1000000   /* (auto selection in batches: set from measurements) */
 int ldc_solver_set_persistent(ldc_solver *s, int mode);
-/* the mode ldc_solver_enqueue will really use for more than one iteration (0, 1, 2 or 3): what set_persistent asked   */
+/* the mode ldc_solver_enqueue will really use for more than one iteration (0, 1, 2, 3 or 4): what set_persistent asked   */
 /* for, resolved against what the handle's size and device allow.  A host that drives several streams uses it to keep  */
 /* launches that need co-resident work-groups (modes 1-3) from overlapping each other.                                 */
 int ldc_solver_mode(ldc_solver *s);
