@@ -2085,11 +2085,12 @@ int launch_xcd(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
 }
 
 // ---- trial-per-CU kernel (mode 4) ------------------------------------------------------------------------------
-constexpr size_t kCuLdsMax = kLdsLimit - 1024;       // (the kernel also has a few static words of LDS)
-template <int T>
+constexpr size_t kCuLdsMax = kLdsLimit - 128;        // (the kernel also has 48 bytes of static LDS: its control block)
+template <int T, bool EDGE>
 int enable_cu_lds_t() {
-  const void* k[3] = {reinterpret_cast<const void*>(cu_kernel<T, false, false>), reinterpret_cast<const void*>(cu_kernel<T, false, true>),
-                      reinterpret_cast<const void*>(cu_kernel<T, true, false>)};
+  const void* k[3] = {reinterpret_cast<const void*>(cu_kernel<T, EDGE, false, false>),
+                      reinterpret_cast<const void*>(cu_kernel<T, EDGE, false, true>),
+                      reinterpret_cast<const void*>(cu_kernel<T, EDGE, true, false>)};
   for (const void* f : k) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCuLdsMax);
     if (e != hipSuccess) return (int)e;
@@ -2098,13 +2099,14 @@ int enable_cu_lds_t() {
 }
 int enable_cu_lds() {
   int e;
-  if ((e = enable_cu_lds_t<1>()) != 0 || (e = enable_cu_lds_t<2>()) != 0 || (e = enable_cu_lds_t<3>()) != 0) return e;
+  if ((e = enable_cu_lds_t<1, false>()) != 0 || (e = enable_cu_lds_t<2, false>()) != 0 || (e = enable_cu_lds_t<3, false>()) != 0 ||
+      (e = enable_cu_lds_t<1, true>()) != 0 || (e = enable_cu_lds_t<2, true>()) != 0) return e;
   return 0;
 }
-// the stage state of the trial, in both orientations, and the four operators fit one CU's LDS
+// the stage state of the trial, in both orientations, and the operators fit one CU's LDS
 bool cu_available(const ldc_solver* s) {
-  const int M = s->p.M, T = (M + 15) / 16;
-  return M >= 3 && M <= kCMaxM && T <= kCT && s->p.LD / 16 >= T && cu_lds_bytes(M) <= kCuLdsMax &&
+  const int M = s->p.M;
+  return M >= 3 && M <= kCMaxM && cu_tiles(M) <= kCT && s->p.LD / 16 >= (M + 15) / 16 && cu_lds_bytes(M) <= kCuLdsMax &&
          s->p.partials_stride >= (int64_t)LDC_NPART;
 }
 bool use_cu(const ldc_solver* s) { return persistent_mode(s) == 4; }
@@ -2124,25 +2126,33 @@ CArgs make_cargs(const ldc_solver* s, int with_diag) {
   a.partZ0 = p.partials + p.partials_stride; a.partP0 = p.partials + 3 * p.partials_stride;
   a.stride = p.partials_stride;
   a.fin = make_final_args(s, with_diag, 1);
+  a.stamps = s->stamps;
   return a;
 }
 
-template <int T>
+template <int T, bool EDGE>
 int cu_launch_t(const CLaunch& cl, bool sp, bool diag, size_t lds_bytes, hipStream_t st) {
-  const dim3 grid(cl.B), block(64 * T * T);
-  if (sp) hipLaunchKernelGGL((cu_kernel<T, true, false>), grid, block, lds_bytes, st, cl);
-  else if (diag) hipLaunchKernelGGL((cu_kernel<T, false, true>), grid, block, lds_bytes, st, cl);
-  else hipLaunchKernelGGL((cu_kernel<T, false, false>), grid, block, lds_bytes, st, cl);
+  const dim3 grid(cl.B), block(64 * (T * T + (EDGE ? 2 : 0)));
+  if (sp) hipLaunchKernelGGL((cu_kernel<T, EDGE, true, false>), grid, block, lds_bytes, st, cl);
+  else if (diag) hipLaunchKernelGGL((cu_kernel<T, EDGE, false, true>), grid, block, lds_bytes, st, cl);
+  else hipLaunchKernelGGL((cu_kernel<T, EDGE, false, false>), grid, block, lds_bytes, st, cl);
   return (int)hipGetLastError();
 }
 int cu_launch_any(const CLaunch& cl, const ldc_solver* s0, int with_diag, hipStream_t st) {
-  const int M = s0->p.M, T = (M + 15) / 16;
+  const int M = s0->p.M, T = cu_tiles(M);
   const bool sp = s0->p.stage_pressure != 0, diag = with_diag != 0;
   const size_t bytes = cu_lds_bytes(M);
+  if (cu_edge(M)) {
+    switch (T) {
+      case 1: return cu_launch_t<1, true>(cl, sp, diag, bytes, st);
+      case 2: return cu_launch_t<2, true>(cl, sp, diag, bytes, st);
+      default: return LDC_E_ARG;
+    }
+  }
   switch (T) {
-    case 1: return cu_launch_t<1>(cl, sp, diag, bytes, st);
-    case 2: return cu_launch_t<2>(cl, sp, diag, bytes, st);
-    case 3: return cu_launch_t<3>(cl, sp, diag, bytes, st);
+    case 1: return cu_launch_t<1, false>(cl, sp, diag, bytes, st);
+    case 2: return cu_launch_t<2, false>(cl, sp, diag, bytes, st);
+    case 3: return cu_launch_t<3, false>(cl, sp, diag, bytes, st);
     default: return LDC_E_ARG;
   }
 }
@@ -2741,7 +2751,7 @@ int ldc_batch_destroy(ldc_batch* b) {
 // Which kernel advances a batch of small trials.  The small-N kernel gives every trial an XCD: 8 (at T'^2 <= 16: up to
 // 8 x floor(32 / T'^2)) trials advance at once, the rest wait; the trial-per-CU kernel advances all of them at once, each
 // several times slower.  Asked for explicitly (mode 4 on every trial) it is taken whenever it applies; in auto mode from
-// LDC_CU_AUTO_TRIALS trials on.
+// LDC_CU_AUTO_TRIALS (ceil(M/16) == 3: LDC_CU_AUTO_TRIALS_T3) trials on.
 bool batch_uses_cu(const ldc_batch* b) {
   bool all_avail = true, all_asked = true, all_auto = true;
   for (const ldc_solver* t : b->s) {
@@ -2751,7 +2761,15 @@ bool batch_uses_cu(const ldc_batch* b) {
   }
   if (!all_avail) return false;
   if (all_asked) return true;
-  return all_auto && b->B >= LDC_CU_AUTO_TRIALS;
+  return all_auto && b->B >= ((b->s[0]->p.M + 15) / 16 >= 3 ? LDC_CU_AUTO_TRIALS_T3 : LDC_CU_AUTO_TRIALS);
+}
+
+int ldc_batch_mode(ldc_batch* b) {
+  if (!b) return LDC_E_STATE;
+  if (batch_uses_cu(b)) return 4;
+  bool all_xcd = true;
+  for (const ldc_solver* t : b->s) all_xcd = all_xcd && use_xcd(t);
+  return all_xcd ? 3 : 0;
 }
 
 int ldc_batch_enqueue(ldc_batch* b, int n_iters, int with_diag, void* stream) {

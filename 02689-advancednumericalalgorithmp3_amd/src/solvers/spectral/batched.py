@@ -131,7 +131,11 @@ class BatchedSGSolver:
         """Enqueue n_iters iterations for every trial; returns per-trial (rows, latch, total)."""
         import torch
         dev = self.solvers[0].device
-        starts = [int(s.d["ctrl"].cpu().numpy()[L.CTRL_ITER]) for s in self.solvers]
+        # (one device-side gather and ONE copy per kind of word for the whole batch: a blocking copy per trial and kind --
+        #  four of them -- was 12 ms of host time per chunk at 256 trials, as much as the chunk itself at N = 16)
+        def words(key):
+            return torch.stack([s.d[key] for s in self.solvers]).cpu().numpy()
+        starts = [int(x) for x in words("ctrl")[:, L.CTRL_ITER]]
         resident = int(n_iters) > 1 and all(L.lib().ldc_solver_mode(s._handle) in (3, 4) for s in self.solvers)
         lock = L.resident_lock(dev.index or 0) if resident else contextlib.nullcontext()
         with lock, torch.cuda.device(dev):        # (see ldc_lib.resident_lock: co-resident launches one at a time per device)
@@ -139,12 +143,15 @@ class BatchedSGSolver:
                     "ldc_batch_enqueue")
             self.solvers[0]._sync()
         out = []
-        for s, start in zip(self.solvers, starts):
-            ctrl = s.d["ctrl"].cpu().numpy()
-            end, done = int(ctrl[L.CTRL_ITER]), int(ctrl[L.CTRL_DONE])
-            ring = s.d["rec"].cpu().numpy()
+        ctrl_all = words("ctrl")
+        gave_up = torch.stack([s.d["sync"][L.SYNC_GIVEUP] for s in self.solvers]).cpu().numpy()
+        same_cap = len({s.rec_cap for s in self.solvers}) == 1
+        rings = words("rec") if same_cap else None
+        for q, (s, start) in enumerate(zip(self.solvers, starts)):
+            end, done = int(ctrl_all[q, L.CTRL_ITER]), int(ctrl_all[q, L.CTRL_DONE])
+            ring = rings[q] if same_cap else s.d["rec"].cpu().numpy()
             out.append((ring[np.arange(start, end) % s.rec_cap], done, end))
-            if int(s.d["sync"][L.SYNC_GIVEUP]) != 0:
+            if int(gave_up[q]) != 0:
                 raise L.LdcError("a persistent launch gave up a barrier wait (a work-group was not resident); the "
                                  "state of the batch is undefined -- rerun with persistent=0")
             if s._edge_fix_pending and end > start:

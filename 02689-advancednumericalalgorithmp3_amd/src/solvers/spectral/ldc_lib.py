@@ -24,7 +24,8 @@ PERSIST_AUTO_XCD_TILES = 0  # LDC_PERSIST_AUTO_XCD_TILES: auto mode picks mode 2
 XCD_TILES = 25              # LDC_XCD_TILES: mode 3 (the small-N trial kernel) runs trials of up to ceil(M/16)^2 = 25 tiles
 XCD_AUTO_TILES = 25         # LDC_XCD_AUTO_TILES: auto mode picks mode 3 up to here
 CU_MAX_M = 44                # LDC_CU_MAX_M: the trial-per-CU kernel (mode 4) holds the stage state of M <= 44 in one CU's LDS
-CU_AUTO_TRIALS = 1000000     # LDC_CU_AUTO_TRIALS: batches of at least this many trials take mode 4 by themselves
+CU_AUTO_TRIALS = 96          # LDC_CU_AUTO_TRIALS: batches of at least this many trials take mode 4 by themselves (ceil(M/16) <= 2)
+CU_AUTO_TRIALS_T3 = 48       # LDC_CU_AUTO_TRIALS_T3: the same for ceil(M/16) == 3
 REC_REL, REC_RU, REC_RV, REC_RP, REC_E, REC_Z, REC_P, REC_DT = range(8)
 CTRL_DONE, CTRL_ITER = 0, 1
 SCAL_DT, SCAL_UMAX, SCAL_VMAX = 0, 1, 2
@@ -86,6 +87,7 @@ def lib() -> C.CDLL:
     L.ldc_solver_set_persistent.argtypes = [_dp, C.c_int]
     L.ldc_solver_status.argtypes = [_dp]
     L.ldc_solver_mode.argtypes = [_dp]
+    L.ldc_batch_mode.argtypes = [_dp]
     L.ldc_stage.argtypes = [_dp, C.c_int, _dp]
     L.ldc_pressure_transform.argtypes = [_dp, C.c_int, _dp]
     L.ldc_diagnostics.argtypes = [_dp, _dp]
@@ -121,7 +123,7 @@ def lib() -> C.CDLL:
 EXPORTS = (
     "ldc_version", "ldc_error_string", "ldc_device_check", "ldc_solver_create", "ldc_solver_destroy",
     "ldc_stage", "ldc_pressure_transform", "ldc_diagnostics", "ldc_finalize", "ldc_prime", "ldc_global_quantities",
-    "ldc_solver_enqueue", "ldc_solver_set_graph_iters", "ldc_solver_set_persistent", "ldc_solver_status", "ldc_solver_mode",
+    "ldc_solver_enqueue", "ldc_solver_set_graph_iters", "ldc_solver_set_persistent", "ldc_solver_status", "ldc_solver_mode", "ldc_batch_mode",
     "ldc_residual_debug", "ldc_gemm_nt",
     "ldc_batch_workspace_bytes", "ldc_batch_create", "ldc_batch_destroy", "ldc_batch_enqueue",
     "ldc_poisson_fastdiag", "ldc_vortex_extrema", "ldc_mfma_selftest", "ldc_mfma_peak", "ldc_debug_ablate", "ldc_debug_stamps",

@@ -42,7 +42,7 @@ def rate(N, B, mode, K):
 print(f"trial-iterations/s, {kind}; columns: launch path | small-N kernel (one trial per XCD) | trial per CU")
 for N in Ns:
     for B in Bs:
-        K = 2048 if B <= 64 else 1024
+        K = 4096         # (a chunk of a sweep: check_every iterations per launch)
         row = []
         for mode in (0, 3, 4):
             if mode == 0 and B > 64:
