@@ -34,6 +34,7 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE J
               "persistent": one launch of the persistent trial kernel).
 * small_n   : BASELINE.json configs[1] (N=64, Re=400) on the same GPU: full iterations per second through the small-N
               trial kernel (what the solver picks by default at N <= 79) and through the launch path (N = 1 only).
+* cu_batch   : 256 trials of N=32 in one batch (N = 1 only): trial-iterations per second through the trial-per-CU kernel.
 * farm      : a second, sweep-shaped measurement for the multi-GPU runs -- every rank advances `trials_per_gpu`
               equal-N trials the way main.py advances the trials a rank owns in the Hydra multirun / Optuna search:
               two batches with shared launches, side by side on two HIP streams of different priority;
@@ -346,6 +347,38 @@ def small_n_block(device, N=64, Re=400.0, K=4096):
 
 
 
+def cu_batch_block(device, N=32, B=256, K=2048):
+    """The other end of the sweep axis on one GPU: MANY small trials (the reference's Optuna study samples N = 30, 40, 50;
+    its fixtures are N = 16, 32).  B trials of size N in one batch: from LDC_CU_AUTO_TRIALS trials on the library advances
+    them with the trial-per-CU kernel (csrc/ldc_cu_kernel.inc: one work-group per trial, stage state in LDS, no hand-over
+    between work-groups); trial-iterations per second over a chunk of K iterations (step()-only loop, host clock around
+    enqueue + wait + the batch-wide copy of the history rows: what a sweep pays per chunk)."""
+    import torch
+    from solvers.spectral import ldc_lib as L
+    from solvers.spectral.batched import BatchedSGSolver
+    # (Re = 100 ... 228: at N = 32 the reference's scheme itself diverges at Re = 1000 after ~2 300 iterations -- the oracle too)
+    trials = [dict(name="spectral", Re=100.0 + 0.5 * q, lid_velocity=1.0, Lx=1.0, Ly=1.0, nx=N, ny=N, tolerance=0.0,
+                   max_iterations=10**9, basis_type="chebyshev", CFL=1.5, beta_squared=5.0, corner_treatment="smoothing",
+                   corner_smoothing=0.02 + 0.0005 * q, multigrid="none", device=device, check_every=K, graph_iters=64)
+              for q in range(B)]
+    b = BatchedSGSolver(trials)
+    b.run_iterations(64, diagnostics=False)
+    mode = int(L.lib().ldc_batch_mode(b._batch))
+    best = 0.0
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        b.run_iterations(K, diagnostics=False)
+        torch.cuda.synchronize()
+        best = max(best, B * K / (time.perf_counter() - t0))
+    rec = b.solvers[B - 1].d["rec"].cpu().numpy()
+    assert bool((rec == rec).all()), "non-finite history record in the batch of small trials"
+    b.close()
+    return {"value": best, "unit": "trial-iterations/s", "N": N, "trials": B, "iterations_per_chunk": K, "batch_mode": mode,
+            "workload": f"{B} SG trials of N={N} in one batch on one GPU (step()-only loop), one work-group per trial"}
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -449,6 +482,7 @@ def main():
         }
         out["farm"] = farm
         out["small_n"] = small_n_block(f"cuda:{local}") if world == 1 else None
+        out["cu_batch"] = cu_batch_block(f"cuda:{local}") if world == 1 else None
         mfma = pmc_mfma_util(a.N, t_stage)
         if mfma is not None:
             out["roofline"].update(mfma)
