@@ -60,7 +60,13 @@ class BatchedSGSolver:
         B = len(self.solvers)
         nbytes = lib.ldc_batch_workspace_bytes(B)
         dev = self.solvers[0].device
-        self._ws = torch.zeros(nbytes + 256, dtype=torch.uint8, device=dev)
+        # The library fills the workspace by synchronous copies on a stream of its own: nothing of OURS may still be on its way
+        # into that memory.  (It used to be torch.zeros: a fill kernel queued on this thread's stream.  Behind a long launch of
+        # another worker -- a chunk of the small-N or trial-per-CU kernel holds the chip for tens of milliseconds -- the fill ran
+        # AFTER the library's copies and wiped the argument blocks: the batch's kernels then read null pointers, "memory access
+        # fault on address (nil)" in a 600-trial search round; never seen while every launch was short.)
+        self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        torch.cuda.current_stream(dev).synchronize()
         base = (self._ws.data_ptr() + 255) & ~255
         arr = (C.c_void_p * B)(*[s._handle for s in self.solvers])
         h = C.c_void_p()
@@ -236,6 +242,8 @@ class BatchedFSGSolver:
         total = [0] * len(fines)
         last = [0] * len(fines)                       # latch of the last level each trial ran
         for idx in range(nlev):
+            if not alive:          # every trial diverged on a coarser level (NaN latch): nothing goes up, as in FSGSolver.solve
+                break
             group = [ladders[q][idx] for q in alive]
             for q, lvl in zip(alive, group):
                 if idx == 0:

@@ -240,7 +240,9 @@ int ldc_solver_status(ldc_solver *s);
 /* identical geometry (M, LD, mode) advanced by the same launches, blockIdx.y = trial; each     */
 /* keeps its own state, dt, latch and history.  `workspace` = caller-owned DEVICE memory,        */
 /* 256-byte aligned, at least ldc_batch_workspace_bytes(n_trials) bytes, alive as long as the    */
-/* batch; it receives the per-trial kernel argument blocks (one synchronous copy at creation).   */
+/* batch; it receives the per-trial kernel argument blocks (one synchronous copy at creation,    */
+/* on a stream of the library's own: NO work of the caller that writes this memory -- not even   */
+/* a fill that zeroes it -- may be pending on any stream when ldc_batch_create is called).         */
 typedef struct ldc_batch ldc_batch;
 size_t ldc_batch_workspace_bytes(int n_trials);
 int ldc_batch_create(ldc_solver *const *solvers, int n_trials, void *workspace, size_t workspace_bytes,

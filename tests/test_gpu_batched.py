@@ -143,6 +143,47 @@ def test_batched_fsg_equals_individual_fsg_solves():
     b.close()
 
 
+def test_batch_workspace_is_not_filled_behind_the_librarys_back():
+    """ldc_batch_create copies the argument blocks into the caller's workspace on a stream of its own.  The workspace used to
+    be a torch.zeros tensor: behind a long launch of another worker thread the fill kernel ran AFTER those copies, wiped the
+    blocks, and the batch's kernels read null pointers (a memory access fault in a 600-trial search round).  The batch must
+    leave nothing of its own pending on the stream when it hands the workspace over -- checked without provoking the fault:
+    a long sleep is queued in front, and the stream is idle when the batch exists."""
+    import torch
+    from solvers.spectral.batched import BatchedSGSolver
+    b = BatchedSGSolver([kw(32, 100.0), kw(32, 200.0)])
+    torch.cuda.synchronize()
+    torch.cuda._sleep(200_000_000)                    # ~0.1 s of an idle kernel on this stream
+    assert not torch.cuda.current_stream().query()
+    b._ensure_batch([0.0, 0.0])
+    assert torch.cuda.current_stream().query()        # whatever the batch queued for its workspace has been waited for
+    rec = b.run_iterations(40)
+    assert np.all(np.isfinite(rec[0])) and np.all(np.isfinite(rec[1]))
+    b.close()
+
+
+def test_batched_fsg_where_every_trial_diverges_on_the_coarse_level():
+    """The reference's Optuna experiment samples N = 30 at Re = 1000 (conf/experiment/optimization/corner_smoothing.yaml): its
+    coarse level N = 15 blows up within a few thousand iterations, the NaN latch ends the trial ("early NaN/Inf detection
+    exits diverging runs quickly") and nothing is prolongated.  A batch whose trials ALL end that way must finish like the
+    stand-alone solves -- same iteration counts, converged = False -- instead of building an empty batch for the next level
+    (found by running that experiment file as it stands: tools/sweep_report.py optuna_ref)."""
+    from solvers.spectral.batched import BatchedFSGSolver
+    from solvers.spectral.fsg import FSGSolver
+    trials = [fsg_kw(30, 1000, 0.03, tolerance=1e-6, max_iterations=500000),
+              fsg_kw(30, 1000, 0.08, tolerance=1e-6, max_iterations=500000)]
+    b = BatchedFSGSolver(trials)
+    assert b.orders == [15, 30]
+    ms = b.solve()
+    for t, m in zip(trials, ms):
+        one = FSGSolver(**t)
+        one.solve()
+        assert not m.converged and not one.metrics.converged
+        assert m.iterations == one.metrics.iterations and 0 < m.iterations < 50000
+        one.close()
+    b.close()
+
+
 def test_batched_fsg_trial_vs_reference_fixture(golden_dir):
     """A batched FSG trial against the reference's own capped two-level run (g8: cap300_N32_Re100)."""
     import json

@@ -3,6 +3,9 @@
 
     python tools/sweep_report.py config4 gpurun_out/sweeps/config4.md
     python tools/sweep_report.py config5 gpurun_out/sweeps/config5.md [n_trials] [n_jobs]
+    python tools/sweep_report.py optuna_ref gpurun_out/sweeps/optuna_ref.md [n_trials] [n_jobs]
+(optuna_ref: the reference's experiment file as it stands -- conf/experiment/optimization/corner_smoothing.yaml: FSG, Re=1000,
+N sampled from {30, 40, 50}, 15 trials in rounds of 5 -- or with more trials per round)
 """
 import importlib.util
 import json
@@ -41,6 +44,12 @@ threading.Thread(target=heartbeat, daemon=True).start()
 t0 = time.perf_counter()
 if which == "config4":
     argv = ["-m", "N=64,128,256", "Re=100,400,1000"]
+elif which == "optuna_ref":
+    argv = ["-m", "+experiment/optimization=corner_smoothing", "optuna.objective=botella_vortex"]
+    if len(sys.argv) > 3:
+        argv.append(f"hydra.sweeper.n_trials={sys.argv[3]}")
+    if len(sys.argv) > 4:
+        argv.append(f"hydra.sweeper.n_jobs={sys.argv[4]}")
 else:
     n_trials = sys.argv[3] if len(sys.argv) > 3 else "64"
     n_jobs = sys.argv[4] if len(sys.argv) > 4 else "8"
@@ -68,13 +77,16 @@ if which == "config4":
                   f"({recs[0].get('solve_streams', 1)} worker stream(s); a batch's own wall time overlaps the others') = "
                   f"{its / secs:.0f} trial-iterations/s."]
 else:
-    lines += ["| trial | corner_smoothing | iterations | converged | objective | psi_min | x | y | batch wall s |",
-              "|---|---|---|---|---|---|---|---|---|"]
+    lines += ["| trial | N | corner_smoothing | iterations | converged | objective | psi_min | x | y | batch wall s |",
+              "|---|---|---|---|---|---|---|---|---|---|"]
     for k, r in enumerate(recs):
+        if "metrics" not in r:
+            lines.append(f"| {k} | {r.get('N', '')} | | | | failed: {str(r.get('error', ''))[:60]} | | | | |")
+            continue
         m = r["metrics"]
-        lines.append(f"| {k} | {r['params']['corner_smoothing']:.4f} | {m['iterations']} | {m['converged']} | {r['objective']:.5f} | "
+        lines.append(f"| {k} | {r['N']} | {r['params']['corner_smoothing']:.4f} | {m['iterations']} | {m['converged']} | {r['objective']:.5f} | "
                      f"{m['psi_min']:.6f} | {m['psi_min_x']:.4f} | {m['psi_min_y']:.4f} | {r.get('solve_pool_seconds', r['batch_seconds']):.1f} |")
-    its = sum(r["metrics"]["iterations"] for r in recs)
+    its = sum(r["metrics"]["iterations"] for r in recs if "metrics" in r)
     lines += ["", f"Best objective {best:.5f}; {its} trial-iterations, {its / wall:.0f} trial-iterations/s end to end."]
 out.write_text("\n".join(lines) + "\n")
 print("\n".join(lines[:6]))
