@@ -2751,7 +2751,7 @@ int ldc_batch_destroy(ldc_batch* b) {
 // Which kernel advances a batch of small trials.  The small-N kernel gives every trial an XCD: 8 (at T'^2 <= 16: up to
 // 8 x floor(32 / T'^2)) trials advance at once, the rest wait; the trial-per-CU kernel advances all of them at once, each
 // several times slower.  Asked for explicitly (mode 4 on every trial) it is taken whenever it applies; in auto mode from
-// LDC_CU_AUTO_TRIALS (ceil(M/16) == 3: LDC_CU_AUTO_TRIALS_T3) trials on.
+// LDC_CU_AUTO_TRIALS (ceil(M/16) == 3: LDC_CU_AUTO_TRIALS_T3; M == 33: LDC_CU_AUTO_TRIALS_M33) trials on.
 bool batch_uses_cu(const ldc_batch* b) {
   bool all_avail = true, all_asked = true, all_auto = true;
   for (const ldc_solver* t : b->s) {
@@ -2761,7 +2761,9 @@ bool batch_uses_cu(const ldc_batch* b) {
   }
   if (!all_avail) return false;
   if (all_asked) return true;
-  return all_auto && b->B >= ((b->s[0]->p.M + 15) / 16 >= 3 ? LDC_CU_AUTO_TRIALS_T3 : LDC_CU_AUTO_TRIALS);
+  const int M = b->s[0]->p.M;
+  const int need = (M == 33) ? LDC_CU_AUTO_TRIALS_M33 : ((M + 15) / 16 >= 3 ? LDC_CU_AUTO_TRIALS_T3 : LDC_CU_AUTO_TRIALS);
+  return all_auto && b->B >= need;
 }
 
 int ldc_batch_mode(ldc_batch* b) {

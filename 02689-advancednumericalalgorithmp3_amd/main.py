@@ -327,6 +327,7 @@ def main(argv=None) -> float | None:
     root_dir = Path(dist.all_gather_object(root_dir)[0])          # every rank uses rank 0's timestamp
 
     SG, FSG = "solvers.spectral.sg.SGSolver", "solvers.spectral.fsg.FSGSolver"
+    batch_cap_given = "LDC_MAX_BATCH" in os.environ or "batch_trials" in (stamp_cfg.get("hydra", {}).get("launcher", {}) or {})
     max_batch = int(os.environ.get("LDC_MAX_BATCH", stamp_cfg.get("hydra", {}).get("launcher", {}).get("batch_trials", 64)))
 
     def job_cfg(assignment, index):
@@ -348,8 +349,12 @@ def main(argv=None) -> float | None:
         groups, where = [], []
         for (target, _, _, _), members in share.items():
             if target in (SG, FSG) and len(members) > 1 and max_batch > 1:
-                for lo in range(0, len(members), max_batch):
-                    part = members[lo: lo + max_batch]
+                # sizes the trial-per-CU kernel holds (M <= 44): one work-group per trial, 256 advance at once -- a larger
+                # batch is a better batch there (unless LDC_MAX_BATCH / hydra.launcher.batch_trials says otherwise)
+                n_of = int(cfgs[members[0]]["N"])
+                cap = max_batch if (batch_cap_given or n_of + 1 > 44) else max(max_batch, 256)
+                for lo in range(0, len(members), cap):
+                    part = members[lo: lo + cap]
                     log.info("batch of %d trials at N=%s on %s", len(part), cfgs[part[0]]["N"], device or "cuda:0")
                     groups.append(([cfgs[q] for q in part], [root_dir / str(offset + items[q][0]) for q in part]))
                     where.append(part)

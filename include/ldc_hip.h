@@ -219,14 +219,16 @@ int ldc_solver_set_graph_iters(ldc_solver *s, int iters_per_graph);
 /* operators live in the CU's LDS, one wave per 16 x 16 tile runs all contractions of its tile, no hand-over between        */
 /* work-groups at all.  Needs M <= LDC_CU_MAX_M (the LDS), else LDC_E_ARG.  For one trial it is slower than mode 3 (one CU   */
 /* instead of up to 25); its place is the BATCH: ldc_batch_enqueue advances all trials of a batch at once with it, one CU   */
-/* each (256 at a time), when every trial asked for mode 4, or in mode -1 from LDC_CU_AUTO_TRIALS(_T3) trials on.  Same    */
+/* each (256 at a time), when every trial asked for mode 4, or in mode -1 from LDC_CU_AUTO_TRIALS(_T3, _M33) trials on.  Same    */
 /* entry and exit state as mode 3 (row-major phi^n in, row-major and packed forms out); trajectories agree with the other   */
 /* paths to rounding.                                                                                                       */
 #define LDC_CU_MAX_M 44
-/* (measured, profiles/r03_cu_ab.log: at N = 16 ... 30 the small-N kernel runs 32 ... 64 trials at once, several per XCD, and  */
-/*  wins up to ~100 trials; at N = 32 ... 43 it runs 8 ... 24 at once and loses from ~48 trials on)                                 */
-#define LDC_CU_AUTO_TRIALS 96        /* ceil(M/16) <= 2                                                  */
-#define LDC_CU_AUTO_TRIALS_T3 48     /* ceil(M/16) == 3                                                  */
+/* (measured, profiles/r03_cu_ab.log: the trial-per-CU kernel scales with the number of trials up to 256, the small-N kernel    */
+/*  saturates where its XCDs are full -- 64 trials at ceil(M/16) <= 2 (5.7 M trial-iterations/s), 8 ... 24 above (1.9 M); the    */
+/*  thresholds are where the two lines cross)                                                                                     */
+#define LDC_CU_AUTO_TRIALS 128       /* ceil(M/16) <= 2                                                  */
+#define LDC_CU_AUTO_TRIALS_T3 80     /* ceil(M/16) == 3                                                  */
+#define LDC_CU_AUTO_TRIALS_M33 40    /* M == 33 (N = 32): four tile waves + two edge waves instead of nine tile waves */
 int ldc_solver_set_persistent(ldc_solver *s, int mode);
 /* the mode ldc_solver_enqueue will really use for more than one iteration (0, 1, 2, 3 or 4): what set_persistent asked   */
 /* for, resolved against what the handle's size and device allow.  A host that drives several streams uses it to keep  */

@@ -51,6 +51,7 @@ def test_python_constants_match_the_header(lib):
     assert val("#define LDC_XCD_TILES") == lib.XCD_TILES and val("#define LDC_XCD_AUTO_TILES") == lib.XCD_AUTO_TILES
     assert val("#define LDC_CU_MAX_M") == lib.CU_MAX_M and val("#define LDC_CU_AUTO_TRIALS ") == lib.CU_AUTO_TRIALS
     assert val("#define LDC_CU_AUTO_TRIALS_T3") == lib.CU_AUTO_TRIALS_T3
+    assert val("#define LDC_CU_AUTO_TRIALS_M33") == lib.CU_AUTO_TRIALS_M33
     assert val("#define LDC_NPART") == lib.NPART and val("#define LDC_ABI_VERSION") == lib.ABI_VERSION
 
 

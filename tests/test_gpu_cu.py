@@ -215,12 +215,13 @@ def test_cu_and_the_other_paths_hand_the_state_to_each_other():
 
 def test_batches_pick_the_kernel_by_their_size():
     """persistent=-1 (the default): a batch of small trials is advanced by the small-N kernel (every trial on an XCD of its
-    own) up to LDC_CU_AUTO_TRIALS(_T3) - 1 trials and by the trial-per-CU kernel from there on; both give the oracle's
+    own) up to LDC_CU_AUTO_TRIALS(_T3, _M33) - 1 trials and by the trial-per-CU kernel from there on; both give the oracle's
     trajectory."""
     from solvers.spectral import ldc_lib as L
     from solvers.spectral.batched import BatchedSGSolver
     for N, B, want in ((16, L.CU_AUTO_TRIALS - 1, 3), (16, L.CU_AUTO_TRIALS, 4), (40, L.CU_AUTO_TRIALS_T3 - 1, 3),
-                       (40, L.CU_AUTO_TRIALS_T3, 4), (48, L.CU_AUTO_TRIALS, 3), (96, 4, 0)):
+                       (40, L.CU_AUTO_TRIALS_T3, 4), (32, L.CU_AUTO_TRIALS_M33 - 1, 3), (32, L.CU_AUTO_TRIALS_M33, 4),
+                       (48, L.CU_AUTO_TRIALS, 3), (96, 4, 0)):
         trials = [dict(name="spectral", Re=100.0 + q, lid_velocity=1.0, Lx=1.0, Ly=1.0, nx=N, ny=N, tolerance=0.0,
                        max_iterations=10**9, basis_type="chebyshev", CFL=1.5, beta_squared=5.0,
                        corner_treatment="smoothing", corner_smoothing=0.15, multigrid="none", check_every=64, graph_iters=16)
