@@ -331,6 +331,7 @@ struct TrialState {
 // ---------------------------------------------------------------------------------------
 struct StageArgs {
   int M, LD, T, tail;
+  int Mx, My;                             // nodes along x / y (nx != ny: the tiling is built for M = max, the arrays are zero padded)
   double nu, beta2, alpha;
   const double *Dx, *D2x, *Dy, *D2y, *IxF, *GxF;
   const double *Uin, *UinT, *Vin, *VinT;  // stage input state
@@ -703,7 +704,10 @@ struct StageLds {
 //        of iteration n and are folded by the finalize block of the next post launch.
 // (the body is a function of its own so that `a` is a by-value copy the compiler can keep in scalar registers; the
 //  tile-resident form of the same stage for the persistent trial kernel is tile_stage below)
-template <bool GPV, bool LAST, bool DUMP, bool BATCH, int DIAG>
+// RECT: nx != ny -- the node classes (wall, lid, interior) come from (a.Mx, a.My) instead of M.  A template parameter, not
+// a run-time one: with the two extra scalars in every instantiation the N=256 iteration was 0.35 us longer on the same box
+// (50.1 -> 50.45 us, profiles/r03_ab_stage_rect.log) -- the square kernels are the code they were.
+template <bool GPV, bool LAST, bool DUMP, bool BATCH, int DIAG, bool RECT = false>
 __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, const int nblk, double* lds) {
   constexpr bool GP = GPV || (DIAG == 2);      // "has a fifth contraction" (grad p or grad omega)
   static_assert(!(GPV && DIAG == 2), "stage 2 of SG carries no pressure contraction");
@@ -927,8 +931,10 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
     // role 0: c0 du/dx, c1 dv/dx, c2 d2u/dx2, c3 d2v/dx2, c4 dp/dx | d(omega)/dx
     // role 1: c0 du/dy, c2 dv/dy, c1 d2u/dy2, c3 d2v/dy2, c4 dp/dy | d(omega)/dy
     auto C = [&](int rl, int q) { return owner ? rsum(rl, q) : esum(rl, ekind, q, eidx); };
-    const bool valid = (i < M) && (j < M);
-    const bool interior = (i >= 1) && (i <= M - 2) && (j >= 1) && (j <= M - 2);
+    // (Mx = My = M except for nx != ny, which runs in the non-tail layout: beyond Mx / My everything is zero padding)
+    const int Mx = RECT ? a.Mx : M, My = RECT ? a.My : M;
+    const bool valid = (i < Mx) && (j < My);
+    const bool interior = (i >= 1) && (i <= Mx - 2) && (j >= 1) && (j <= My - 2);
     const bool full = owner || VEL == 1;      // all four velocity contractions are available here
     double ux = 0, vx = 0, uy = 0, vy = 0, lu = 0, lv = 0;
     if (full) {
@@ -977,8 +983,8 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
       un = nm_madd(adt, Ru, u0); vn = nm_madd(adt, Rv, v0);
       // walls first, lid last (sg.py:348-385): the lid row wins the two top corners
       if (!valid) { un = 0.0; vn = 0.0; }
-      else if (j == M - 1) { un = lidv; vn = 0.0; }
-      else if (i == 0 || i == M - 1 || j == 0) { un = 0.0; vn = 0.0; }
+      else if (j == My - 1) { un = lidv; vn = 0.0; }
+      else if (i == 0 || i == Mx - 1 || j == 0) { un = 0.0; vn = 0.0; }
       if (a.rm_out) {
         st_out(a.Uout + ij, un, a.wt);
         st_out(a.Vout + ij, vn, a.wt);
@@ -1085,13 +1091,13 @@ __device__ __forceinline__ void stage_body(const StageArgs a, const int bx, cons
   LDC_STAMP(6);
 }
 
-template <bool GPV, bool LAST, bool DUMP, bool BATCH, int DIAG>
+template <bool GPV, bool LAST, bool DUMP, bool BATCH, int DIAG, bool RECT = false>
 __global__ __launch_bounds__(kStageThreads, 2) void stage_kernel(const StageArgs a_val, const StageArgs* a_arr) {
   // by value: with a reference into device memory (BATCH) every write-through store made the compiler re-load the
   // fields it needs next (+3 us per launch)
   const StageArgs a = BATCH ? a_arr[blockIdx.y] : a_val;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  stage_body<GPV, LAST, DUMP, BATCH, DIAG>(a, (int)blockIdx.x, (int)gridDim.x, lds);
+  stage_body<GPV, LAST, DUMP, BATCH, DIAG, RECT>(a, (int)blockIdx.x, (int)gridDim.x, lds);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1596,15 +1602,15 @@ __device__ __forceinline__ void take_max(Best& b, double v, int idx) {
 }
 
 __global__ __launch_bounds__(1024) void extrema_kernel(const double* Psi, const double* W, const double* x,
-                                                      const double* y, int M, int LD, double* out_val,
+                                                      const double* y, int M, int My, int LD, double* out_val,
                                                       int32_t* out_idx) {
   __shared__ double sv[5][1024];
   __shared__ int si[5][1024];
   const int t = threadIdx.x;
   const double inf = __builtin_huge_val();
   Best b[5] = {{inf, 0x7fffffff}, {-inf, 0x7fffffff}, {-inf, 0x7fffffff}, {-inf, 0x7fffffff}, {-inf, 0x7fffffff}};
-  for (int q = t; q < M * M; q += 1024) {
-    const int i = q / M, j = q % M;
+  for (int q = t; q < M * My; q += 1024) {       // (M x My nodes: x index i < M, y index j < My)
+    const int i = q / My, j = q % My;
     const int idx = i * LD + j;
     const double p = Psi[idx], w = W[idx], xi = x[i], yj = y[j];
     take_min(b[0], p, q);
@@ -1627,7 +1633,7 @@ __global__ __launch_bounds__(1024) void extrema_kernel(const double* Psi, const 
   }
   if (t < 5) {
     const int q = si[t][0];
-    const int i = q / M, j = q % M;
+    const int i = q / My, j = q % My;
     out_idx[t] = i * LD + j;
     out_val[t] = (t == 1) ? W[i * LD + j] : sv[t][0];
   }
@@ -1737,6 +1743,7 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
   StageArgs a;
   memset(&a, 0, sizeof(a));
   a.M = p.M; a.LD = p.LD; a.T = p.T; a.tail = p.tail;
+  a.Mx = p.Mx > 0 ? p.Mx : p.M; a.My = p.My > 0 ? p.My : p.M;
   a.nu = p.nu; a.beta2 = p.beta2;
   static const double alphas[4] = {0.25, 1.0 / 3.0, 0.5, 1.0};   // sg.py:430
   a.alpha = alphas[k];
@@ -1789,8 +1796,12 @@ StageArgs make_stage_args(const ldc_solver* s, int k) {
 // first ldc_solver_create / ldc_batch_create there (ensure_kernel_attributes), so a launch itself touches nothing but its arguments.
 template <bool GP, bool LAST, bool DUMP, bool BATCH, int DIAG>
 int enable_stage_lds() {
-  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(stage_kernel<GP, LAST, DUMP, BATCH, DIAG>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stage_kernel<GP, LAST, DUMP, BATCH, DIAG, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+  if (e != hipSuccess) return (int)e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(stage_kernel<GP, LAST, DUMP, BATCH, DIAG, true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+  return (int)e;
 }
 template <bool BATCH>
 int enable_stage_lds_all() {
@@ -1806,33 +1817,34 @@ int enable_stage_lds_all() {
 }
 
 template <bool GP, bool LAST, bool DUMP, bool BATCH, int DIAG>
-int launch_stage_kernel(const StageArgs& a, const StageArgs* arr, int nt, int nbatch, hipStream_t st) {
-  auto kern = stage_kernel<GP, LAST, DUMP, BATCH, DIAG>;
+int launch_stage_kernel(const StageArgs& a, const StageArgs* arr, int nt, int nbatch, hipStream_t st, bool rect) {
   constexpr size_t lds_bytes = StageLds<GP || DIAG == 2, GP || DIAG != 0 || LAST || DUMP>::BYTES;
   static_assert(lds_bytes <= kLdsLimit, "stage kernel LDS");
-  hipLaunchKernelGGL(kern, dim3(nt, nbatch), dim3(kStageThreads), lds_bytes, st, a, arr);
+  // (rect: nx != ny; a batch has one geometry, so the caller's flag holds for every trial of it)
+  if (rect) hipLaunchKernelGGL((stage_kernel<GP, LAST, DUMP, BATCH, DIAG, true>), dim3(nt, nbatch), dim3(kStageThreads), lds_bytes, st, a, arr);
+  else hipLaunchKernelGGL((stage_kernel<GP, LAST, DUMP, BATCH, DIAG, false>), dim3(nt, nbatch), dim3(kStageThreads), lds_bytes, st, a, arr);
   return (int)hipGetLastError();
 }
 
 // which instantiation runs RK stage k (diag: fuse the omega / palinstrophy work into stages 1 and 2)
 template <bool BATCH>
 int launch_stage_any(const StageArgs& a, const StageArgs* arr, int k, bool stage_pressure, bool diag, int nt,
-                     int nbatch, hipStream_t st) {
+                     int nbatch, hipStream_t st, bool rect) {
   if (stage_pressure) {   // FSG smoother: every stage differentiates its own input pressure; no diagnostics
-    if (k < 3) return launch_stage_kernel<true, false, false, BATCH, 0>(a, arr, nt, nbatch, st);
-    return launch_stage_kernel<true, true, false, BATCH, 0>(a, arr, nt, nbatch, st);
+    if (k < 3) return launch_stage_kernel<true, false, false, BATCH, 0>(a, arr, nt, nbatch, st, rect);
+    return launch_stage_kernel<true, true, false, BATCH, 0>(a, arr, nt, nbatch, st, rect);
   }
-  if (k == 0) return diag ? launch_stage_kernel<true, false, false, BATCH, 1>(a, arr, nt, nbatch, st)
-                          : launch_stage_kernel<true, false, false, BATCH, 0>(a, arr, nt, nbatch, st);
-  if (k == 1) return diag ? launch_stage_kernel<false, false, false, BATCH, 2>(a, arr, nt, nbatch, st)
-                          : launch_stage_kernel<false, false, false, BATCH, 0>(a, arr, nt, nbatch, st);
-  if (k == 2) return launch_stage_kernel<false, false, false, BATCH, 0>(a, arr, nt, nbatch, st);
-  return launch_stage_kernel<false, true, false, BATCH, 0>(a, arr, nt, nbatch, st);
+  if (k == 0) return diag ? launch_stage_kernel<true, false, false, BATCH, 1>(a, arr, nt, nbatch, st, rect)
+                          : launch_stage_kernel<true, false, false, BATCH, 0>(a, arr, nt, nbatch, st, rect);
+  if (k == 1) return diag ? launch_stage_kernel<false, false, false, BATCH, 2>(a, arr, nt, nbatch, st, rect)
+                          : launch_stage_kernel<false, false, false, BATCH, 0>(a, arr, nt, nbatch, st, rect);
+  if (k == 2) return launch_stage_kernel<false, false, false, BATCH, 0>(a, arr, nt, nbatch, st, rect);
+  return launch_stage_kernel<false, true, false, BATCH, 0>(a, arr, nt, nbatch, st, rect);
 }
 
 int launch_stage(ldc_solver* s, int k, int diag, hipStream_t st) {
   const StageArgs a = make_stage_args(s, k);
-  return launch_stage_any<false>(a, nullptr, k, s->p.stage_pressure != 0, diag != 0, s->nt, 1, st);
+  return launch_stage_any<false>(a, nullptr, k, s->p.stage_pressure != 0, diag != 0, s->nt, 1, st, s->p.Mx != s->p.My);
 }
 
 FinalArgs make_final_args(const ldc_solver* s, int with_diag, int do_critical) {
@@ -1959,7 +1971,7 @@ int enable_trial_lds() {
 // every work-group of a trial must be resident at once (one per CU: the LDS carve allows no second one)
 bool persistent_available(const ldc_solver* s) {
 #ifdef LDC_TIMING
-  return s->p.sync != nullptr && s->nt <= s->n_cus && s->ablate == 0;
+  return s->p.sync != nullptr && s->nt <= s->n_cus && s->ablate == 0 && s->p.Mx == s->p.My;
 #else
   (void)s;
   return false;               // modes 1 and 2 exist in the instrumented build only (ldc_trial_kernel.inc)
@@ -2010,7 +2022,7 @@ int xcd_tiles(const ldc_solver* s) { return (s->p.M + 15) / 16; }
 // every tile's work-group on one XCD, one per CU; the packed arrays hold T x T blocks; a partial-sum row per tile
 bool xcd_available(const ldc_solver* s) {
   const int T = xcd_tiles(s);
-  return s->p.sync != nullptr && T <= kXT && T * T <= s->n_cus / s->n_xcds && s->p.LD / 16 >= T &&
+  return s->p.sync != nullptr && s->p.Mx == s->p.My && T <= kXT && T * T <= s->n_cus / s->n_xcds && s->p.LD / 16 >= T &&
          s->p.partials_stride >= (int64_t)T * T * LDC_NPART;
 }
 bool use_xcd(const ldc_solver* s) { return persistent_mode(s) == 3; }
@@ -2106,7 +2118,7 @@ int enable_cu_lds() {
 // the stage state of the trial, in both orientations, and the operators fit one CU's LDS
 bool cu_available(const ldc_solver* s) {
   const int M = s->p.M;
-  return M >= 3 && M <= kCMaxM && cu_tiles(M) <= kCT && s->p.LD / 16 >= (M + 15) / 16 && cu_lds_bytes(M) <= kCuLdsMax &&
+  return s->p.Mx == s->p.My && M >= 3 && M <= kCMaxM && cu_tiles(M) <= kCT && s->p.LD / 16 >= (M + 15) / 16 && cu_lds_bytes(M) <= kCuLdsMax &&
          s->p.partials_stride >= (int64_t)LDC_NPART;
 }
 bool use_cu(const ldc_solver* s) { return persistent_mode(s) == 4; }
@@ -2333,7 +2345,8 @@ size_t batch_bytes(int B) {
 int batch_launch_stage(ldc_batch* b, int k, int diag, hipStream_t st) {
   const ldc_solver* s0 = b->s[0];
   const StageArgs dummy = {};
-  return launch_stage_any<true>(dummy, b->d_stage[k], k, s0->p.stage_pressure != 0, diag != 0, s0->nt, b->B, st);
+  return launch_stage_any<true>(dummy, b->d_stage[k], k, s0->p.stage_pressure != 0, diag != 0, s0->nt, b->B, st,
+                                s0->p.Mx != s0->p.My);
 }
 
 int batch_launch_iteration(ldc_batch* b, int with_diag, hipStream_t st) {
@@ -2431,6 +2444,13 @@ int ldc_solver_create(const ldc_problem* d, ldc_solver** out) {
   if (!lay_a && !lay_b) return LDC_E_ARG;
   if (d->rec_cap < 1 || (d->stage_pressure != 0 && d->stage_pressure != 1)) return LDC_E_ARG;
   if (d->tail && d->T > 16) return LDC_E_ARG;   // the index-(M-1) jobs stage four groups per wave
+  {
+    // nx != ny: M is the larger of the two node counts (the tiling), everything beyond Mx / My is zero padding; index
+    // M-1 must lie inside the tiles (no tail layout: its rank-1 paths assume the last index of BOTH axes)
+    const int Mx = d->Mx > 0 ? d->Mx : d->M, My = d->My > 0 ? d->My : d->M;
+    if (Mx < 4 || My < 4 || (Mx > My ? Mx : My) != d->M) return LDC_E_ARG;
+    if (Mx != My && d->tail) return LDC_E_ARG;
+  }
   if (d->stage_pressure && (!d->PA || !d->PB || !d->PAK || !d->PBK)) return LDC_E_ARG;
   const void* req[] = {d->Dx, d->D2x, d->Dy, d->D2y, d->IxF, d->GxF, d->IyF, d->GyF, d->wx, d->wy, d->ulid,
                        d->DxL, d->D2xL, d->DyL, d->D2yL,
@@ -2451,6 +2471,8 @@ int ldc_solver_create(const ldc_problem* d, ldc_solver** out) {
   ldc_solver* s = new (std::nothrow) ldc_solver;
   if (!s) return LDC_E_STATE;
   s->p = *d;
+  if (s->p.Mx <= 0) s->p.Mx = d->M;
+  if (s->p.My <= 0) s->p.My = d->M;
   s->device = dev;
   s->n_cus = n_cus;
   s->n_xcds = n_cus >= 64 ? n_cus / 32 : 1;
@@ -2648,6 +2670,7 @@ int ldc_batch_create(ldc_solver* const* solvers, int n_trials, void* workspace, 
     if (!t) return LDC_E_STATE;
     // one geometry, one tiling and one device for all: every launch takes its grid from solver 0
     if (t->p.M != s0->p.M || t->p.LD != s0->p.LD || t->p.stage_pressure != s0->p.stage_pressure) return LDC_E_ARG;
+    if (t->p.Mx != s0->p.Mx || t->p.My != s0->p.My) return LDC_E_ARG;
     if (t->p.T != s0->p.T || t->p.tail != s0->p.tail || t->nt != s0->nt || t->n_edge_blocks != s0->n_edge_blocks ||
         t->n_pedge_blocks != s0->n_pedge_blocks || t->device != s0->device)
       return LDC_E_ARG;
@@ -2852,7 +2875,7 @@ int ldc_residual_debug(ldc_solver* s, int which, double* const out[11], void* st
   if (e) return e;
   StageArgs a = make_stage_args(s, which == 0 ? 0 : which == 1 ? 1 : 2);
   for (int q = 0; q < 11; ++q) a.dump[q] = out[q];
-  return launch_stage_kernel<true, false, true, false, 0>(a, nullptr, s->nt, 1, st);
+  return launch_stage_kernel<true, false, true, false, 0>(a, nullptr, s->nt, 1, st, s->p.Mx != s->p.My);
 }
 
 int ldc_gemm_nt(const double* A, const double* B, double* C, int R16, int K16, int LD, int transpose_out,
@@ -2880,11 +2903,15 @@ int ldc_poisson_fastdiag(const double* Qx, const double* Qxinv, const double* Qy
   return ldc_gemm_nt(Qx, w0, Psi, R, R, LD, 0, 0, nullptr, nullptr, stream);
 }
 
+int ldc_vortex_extrema_xy(const double* Psi, const double* W, const double* x, const double* y, int Mx, int My, int LD,
+                          double* out_val, int32_t* out_idx, void* stream) {
+  if (!Psi || !W || !x || !y || !out_val || !out_idx || Mx < 2 || My < 2 || LD < Mx || LD < My) return LDC_E_ARG;
+  hipLaunchKernelGGL(extrema_kernel, dim3(1), dim3(1024), 0, as_stream(stream), Psi, W, x, y, Mx, My, LD, out_val, out_idx);
+  return (int)hipGetLastError();
+}
 int ldc_vortex_extrema(const double* Psi, const double* W, const double* x, const double* y, int M, int LD,
                        double* out_val, int32_t* out_idx, void* stream) {
-  if (!Psi || !W || !x || !y || !out_val || !out_idx || M < 2 || LD < M) return LDC_E_ARG;
-  hipLaunchKernelGGL(extrema_kernel, dim3(1), dim3(1024), 0, as_stream(stream), Psi, W, x, y, M, LD, out_val, out_idx);
-  return (int)hipGetLastError();
+  return ldc_vortex_extrema_xy(Psi, W, x, y, M, M, LD, out_val, out_idx, stream);
 }
 
 int ldc_mfma_selftest(const double* A, const double* B, double* D, void* stream) {

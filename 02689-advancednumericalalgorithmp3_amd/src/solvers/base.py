@@ -217,9 +217,12 @@ class LidDrivenCavitySolver(ABC):
 
     def ghia_error(self) -> dict:
         """Centreline error against Ghia et al. 1982 (SURVEY.md 8d Metric 2)."""
-        M = int(round(np.sqrt(self.fields.x.size)))
-        x, y = self.fields.x.reshape(M, M)[:, 0], self.fields.y.reshape(M, M)[0, :]
-        return _val.ghia_centerline_error(x, y, self.fields.u.reshape(M, M), self.fields.v.reshape(M, M),
+        shape = getattr(self, "shape_full", None)          # (nodes along x, nodes along y); nx != ny allowed
+        if shape is None:
+            M = int(round(np.sqrt(self.fields.x.size)))
+            shape = (M, M)
+        x, y = self.fields.x.reshape(shape)[:, 0], self.fields.y.reshape(shape)[0, :]
+        return _val.ghia_centerline_error(x, y, self.fields.u.reshape(shape), self.fields.v.reshape(shape),
                                           int(self.params.Re))
 
     def validation_table(self) -> list:

@@ -38,6 +38,13 @@ def hierarchy_orders(n_fine: int, n_levels: int, coarsest_n: int = COARSEST_N) -
 
 
 class FSGSolver(SGSolver):
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        if self.params.nx != self.params.ny:
+            # the reference builds its level hierarchy from ONE order (multigrid/fsg.py:490-530, n_fine = nx) and squares
+            # every level; with nx != ny it has no defined behaviour to reproduce
+            raise NotImplementedError("FSG needs nx == ny (the level hierarchy is built from one polynomial order)")
+
     def _smoother_mode(self):
         self._stage_pressure, self._warmup, self._nan_exit = 1, 0, True
 

@@ -55,6 +55,7 @@ class Problem(C.Structure):
             "partials")]
         + [("partials_stride", C.c_int64)]
         + [(n, _dp) for n in ("scal", "ctrl", "rec", "sync")]
+        + [("Mx", C.c_int32), ("My", C.c_int32)]
     )
 
 
@@ -105,6 +106,7 @@ def lib() -> C.CDLL:
     L.ldc_gemm_nt.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
     L.ldc_poisson_fastdiag.argtypes = [_dp] * 10 + [C.c_int, C.c_int, _dp]
     L.ldc_vortex_extrema.argtypes = [_dp, _dp, _dp, _dp, C.c_int, C.c_int, _dp, _dp, _dp]
+    L.ldc_vortex_extrema_xy.argtypes = [_dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp]
     L.ldc_pack.argtypes = [_dp, _dp, C.c_int, _dp]
     L.ldc_debug_ablate.argtypes = [_dp, C.c_int]
     L.ldc_debug_stamps.argtypes = [_dp, C.c_void_p]
@@ -127,7 +129,7 @@ EXPORTS = (
     "ldc_solver_enqueue", "ldc_solver_set_graph_iters", "ldc_solver_set_persistent", "ldc_solver_status", "ldc_solver_mode", "ldc_batch_mode",
     "ldc_residual_debug", "ldc_gemm_nt",
     "ldc_batch_workspace_bytes", "ldc_batch_create", "ldc_batch_destroy", "ldc_batch_enqueue",
-    "ldc_poisson_fastdiag", "ldc_vortex_extrema", "ldc_mfma_selftest", "ldc_mfma_peak", "ldc_debug_ablate", "ldc_debug_stamps",
+    "ldc_poisson_fastdiag", "ldc_vortex_extrema", "ldc_vortex_extrema_xy", "ldc_mfma_selftest", "ldc_mfma_peak", "ldc_debug_ablate", "ldc_debug_stamps",
     "ldc_pack", "ldc_stream_priority_range", "ldc_stream_create", "ldc_stream_destroy", "ldc_timing_build",
 )
 

@@ -77,14 +77,12 @@ class SGSolver(LidDrivenCavitySolver):
             self.basis_y = LegendreLobattoBasis(domain=(0.0, p.Ly))
         else:
             raise ValueError(f"Unknown basis_type: {p.basis_type}. Use 'legendre' or 'chebyshev'")
-        if p.nx != p.ny:
-            raise NotImplementedError("the HIP path needs nx == ny (all reference configs set both to N)")
         self.corner_treatment = create_corner_treatment(
             method=p.corner_treatment, smoothing_width=p.corner_smoothing)
 
         self._build_operators()
-        self.shape_full = (self.M, self.M)
-        self.shape_inner = (self.M - 2, self.M - 2)
+        self.shape_full = (self.Mx, self.My)
+        self.shape_inner = (self.Mx - 2, self.My - 2)
         self._init_fields(x=self.x_full.ravel(), y=self.y_full.ravel())
         self._alloc_device()
         self.arrays = _ArraysView(self)
@@ -101,10 +99,15 @@ class SGSolver(LidDrivenCavitySolver):
     # ------------------------------------------------------------------ host-side setup
     def _build_operators(self):
         p = self.params
-        M = p.nx + 1
-        self.M = M
-        x = self.basis_x.nodes(M)
-        y = self.basis_y.nodes(M)
+        # Independent x / y grids (reference sg.py:103-119).  nx != ny: the device arrays, the tiling and LD are built for
+        # M = max(Mx, My); operators, vectors and fields of the shorter axis are zero padded like everything beyond M, the
+        # kernels take the node classes (wall, lid, interior) from (Mx, My), and the launch-per-stage path runs in the
+        # layout that keeps index M-1 inside the tiles (include/ldc_hip.h, ldc_problem::Mx).
+        Mx, My = p.nx + 1, p.ny + 1
+        M = max(Mx, My)
+        self.M, self.Mx, self.My = M, Mx, My
+        x = self.basis_x.nodes(Mx)
+        y = self.basis_y.nodes(My)
         self.x_nodes, self.y_nodes = x, y
         self.x_full, self.y_full = np.meshgrid(x, y, indexing="ij")
         self.dx_min = float(np.min(np.diff(x)))
@@ -115,8 +118,8 @@ class SGSolver(LidDrivenCavitySolver):
         self.Dyy_1d = self.Dy_1d @ self.Dy_1d
         self.Interp_x = inner_to_full_interpolation(x[1:-1], x)
         self.Interp_y = inner_to_full_interpolation(y[1:-1], y)
-        self.w_x = self.basis_x.quadrature_weights(M)
-        self.w_y = self.basis_y.quadrature_weights(M)
+        self.w_x = self.basis_x.quadrature_weights(Mx)
+        self.w_y = self.basis_y.quadrature_weights(My)
         u_lid, _ = self.corner_treatment.get_lid_velocity(
             x, np.full_like(x, p.Ly), lid_velocity=p.lid_velocity, Lx=p.Lx, Ly=p.Ly)
         self.u_lid = u_lid
@@ -124,7 +127,7 @@ class SGSolver(LidDrivenCavitySolver):
         # (N a multiple of 16 up to 256: index M-1 stays outside the tiles so that T*T work-groups fill
         #  the chip exactly; beyond that the grid is large anyway and index M-1 gets a tile row of its own)
         self.T = (M - 1 + 15) // 16
-        self.tail = 1 if (16 * self.T == M - 1 and self.T <= 16) else 0
+        self.tail = 1 if (16 * self.T == M - 1 and self.T <= 16 and Mx == My) else 0
         if 16 * self.T == M - 1 and not self.tail:
             self.T += 1
         self.LD = 16 * self.T + 16
@@ -160,16 +163,16 @@ class SGSolver(LidDrivenCavitySolver):
             pad[: a.shape[0], : a.shape[1]] = a
             self.d[name].copy_(torch.from_numpy(pad))
 
-        IxF = np.zeros((M, M)); IxF[:, 1:-1] = self.Interp_x
-        IyF = np.zeros((M, M)); IyF[:, 1:-1] = self.Interp_y
+        IxF = np.zeros((self.Mx, self.Mx)); IxF[:, 1:-1] = self.Interp_x
+        IyF = np.zeros((self.My, self.My)); IyF[:, 1:-1] = self.Interp_y
         # The interpolant through the inner nodes evaluated AT an inner node is that node's value: rows 1 .. M-2 are unit
         # rows up to the rounding of V_full V_inner^-1 (1e-15).  They are set exactly (include/ldc_hip.h: the small-N trial
         # kernel contracts GxF with p itself off the ring); anything but rounding there would be a different operator.
         for F in (IxF, IyF):
             inner = F[1:-1, 1:-1]
-            if np.max(np.abs(inner - np.eye(M - 2))) > 1e-9:
+            if np.max(np.abs(inner - np.eye(inner.shape[0]))) > 1e-9:
                 raise ValueError("inner-to-full interpolation is not the identity on the inner nodes")
-            inner[...] = np.eye(M - 2)
+            inner[...] = np.eye(inner.shape[0])
         for name, a in (("Dx", self.Dx_1d), ("D2x", self.Dxx_1d), ("Dy", self.Dy_1d), ("D2y", self.Dyy_1d),
                         ("IxF", IxF), ("GxF", self.Dx_1d @ IxF), ("IyF", IyF), ("GyF", self.Dy_1d @ IyF)):
             up(name, a)
@@ -178,7 +181,7 @@ class SGSolver(LidDrivenCavitySolver):
                         ("x", self.x_nodes), ("y", self.y_nodes),
                         ("DxL", self.Dx_1d[:, -1]), ("D2xL", self.Dxx_1d[:, -1]),
                         ("DyL", self.Dy_1d[:, -1]), ("D2yL", self.Dyy_1d[:, -1])):
-            pad = np.zeros(LD); pad[:M] = v
+            pad = np.zeros(LD); pad[: len(v)] = v
             self.d[name].copy_(torch.from_numpy(pad))
 
     def _abi(self, fn: str, *args):
@@ -199,7 +202,7 @@ class SGSolver(LidDrivenCavitySolver):
     def _download_full(self, name: str) -> np.ndarray:
         import torch
         self._sync()
-        return self.d[name][: self.M, : self.M].cpu().numpy()
+        return self.d[name][: self.Mx, : self.My].cpu().numpy()
 
     def _upload_full(self, name: str, a2d: np.ndarray, transposed_name: str = None):
         import torch
@@ -212,14 +215,14 @@ class SGSolver(LidDrivenCavitySolver):
 
     def set_state(self, u=None, v=None, p=None):
         """Upload (flat or 2-D) host arrays; p lives on the (N-1)^2 inner grid."""
-        M = self.M
+        Mx, My = self.Mx, self.My
         if u is not None:
-            self._upload_full("U", np.asarray(u, float).reshape(M, M), "UT")
+            self._upload_full("U", np.asarray(u, float).reshape(Mx, My), "UT")
         if v is not None:
-            self._upload_full("V", np.asarray(v, float).reshape(M, M), "VT")
+            self._upload_full("V", np.asarray(v, float).reshape(Mx, My), "VT")
         if p is not None:
-            full = np.zeros((M, M))
-            full[1:-1, 1:-1] = np.asarray(p, float).reshape(M - 2, M - 2)
+            full = np.zeros((Mx, My))
+            full[1:-1, 1:-1] = np.asarray(p, float).reshape(Mx - 2, My - 2)
             self._upload_full("P", full)
         for src, dsts in (("U", ("UA", "UB")), ("UT", ("UAT", "UBT")), ("V", ("VA", "VB")),
                           ("VT", ("VAT", "VBT")), ("P", ("PA", "PB"))):
@@ -249,21 +252,21 @@ class SGSolver(LidDrivenCavitySolver):
 
     def set_state_device(self, u, v, p_inner):
         """Same as set_state for torch tensors already on the device ((M,M), (M,M), (M-2,M-2))."""
-        M = self.M
+        Mx, My = self.Mx, self.My
         for name, tname, a in (("U", "UT", u), ("V", "VT", v)):
             self.d[name].zero_(); self.d[tname].zero_()
-            self.d[name][:M, :M] = a
-            self.d[tname][:M, :M] = a.t()
+            self.d[name][:Mx, :My] = a
+            self.d[tname][:My, :Mx] = a.t()
         self.d["P"].zero_()
-        self.d["P"][1: M - 1, 1: M - 1] = p_inner
+        self.d["P"][1: Mx - 1, 1: My - 1] = p_inner
         self.set_state()
 
     def reset_state(self):
         """Fluid at rest with the regularised lid (reference sg.py:76-98)."""
-        M = self.M
-        u = np.zeros((M, M))
+        Mx, My = self.Mx, self.My
+        u = np.zeros((Mx, My))
         u[:, -1] = self.u_lid
-        self.set_state(u=u, v=np.zeros((M, M)), p=np.zeros((M - 2, M - 2)))
+        self.set_state(u=u, v=np.zeros((Mx, My)), p=np.zeros((Mx - 2, My - 2)))
         self.d["ctrl"].zero_()
         self.d["scal"].zero_()
 
@@ -272,6 +275,7 @@ class SGSolver(LidDrivenCavitySolver):
         p = self.params
         pr = L.Problem()
         pr.M, pr.LD, pr.T, pr.tail = self.M, self.LD, self.T, self.tail
+        pr.Mx, pr.My = self.Mx, self.My
         pr.nu, pr.beta2, pr.cfl = 1.0 / p.Re, p.beta_squared, p.CFL
         pr.hx_min, pr.hy_min, pr.lid_speed, pr.tol = self.dx_min, self.dy_min, p.lid_velocity, tol
         nan_exit = bool(p.nan_guard) if self._nan_exit is None else bool(self._nan_exit)
@@ -438,10 +442,9 @@ class SGSolver(LidDrivenCavitySolver):
         arr = (C.c_void_p * 11)(*[t.data_ptr() for t in outs])
         self._abi("ldc_residual_debug", self._handle, which, arr)
         self._sync()
-        M = self.M
         res = {}
         for k, key in enumerate(_DEBUG_KEYS):
-            a = outs[k][:M, :M].cpu().numpy()
+            a = outs[k][: self.Mx, : self.My].cpu().numpy()
             res[key] = a[1:-1, 1:-1].ravel().copy() if key == "R_p" else a.ravel()
         return res
 
@@ -490,26 +493,26 @@ class SGSolver(LidDrivenCavitySolver):
         import torch
         Q = self._eigenbasis()
         self._compute_vorticity()
-        M, Mi = self.M, self.M - 2
+        Mx, My, Mi = self.Mx, self.My, self.M - 2          # (Mi: the larger inner block; the eigenbases are zero padded)
         F, w0, w1, Psi = self.d["S0"], self.d["S1"], self.d["S2"], self.d["S3"]
         F.zero_()
-        F[:Mi, :Mi] = -self.d["W"][1: M - 1, 1: M - 1]
+        F[: Mx - 2, : My - 2] = -self.d["W"][1: Mx - 1, 1: My - 1]
         self._abi("ldc_poisson_fastdiag",
                   Q[0].data_ptr(), Q[1].data_ptr(), Q[2].data_ptr(), Q[3].data_ptr(),
                   self.d["lamx"].data_ptr(), self.d["lamy"].data_ptr(), F.data_ptr(), w0.data_ptr(),
                   w1.data_ptr(), Psi.data_ptr(), Mi, self.LD)
         full = self.d["S4"]
         full.zero_()
-        full[1: M - 1, 1: M - 1] = Psi[:Mi, :Mi]
+        full[1: Mx - 1, 1: My - 1] = Psi[: Mx - 2, : My - 2]
         self._sync()
-        return full[:M, :M].cpu().numpy(), self.x_full, self.y_full
+        return full[:Mx, :My].cpu().numpy(), self.x_full, self.y_full
 
     def compute_vortex_metrics(self) -> dict:
         import torch
         self._compute_streamfunction()          # leaves psi in S4 and omega in W
-        self._abi("ldc_vortex_extrema",
+        self._abi("ldc_vortex_extrema_xy",
                   self.d["S4"].data_ptr(), self.d["W"].data_ptr(), self.d["x"].data_ptr(), self.d["y"].data_ptr(),
-                  self.M, self.LD, self.d["ext_val"].data_ptr(), self.d["ext_idx"].data_ptr())
+                  self.Mx, self.My, self.LD, self.d["ext_val"].data_ptr(), self.d["ext_idx"].data_ptr())
         self._sync()
         val = self.d["ext_val"].cpu().numpy()
         idx = self.d["ext_idx"].cpu().numpy()

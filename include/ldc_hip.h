@@ -155,6 +155,11 @@ typedef struct ldc_problem {
   double  *rec;       /* rec_cap * LDC_REC_LEN doubles, ring indexed by iteration       */
   uint32_t *sync;     /* LDC_SYNC_LEN uint32 (256-byte aligned) for the persistent trial kernel, or NULL:
                          the launch-per-stage path is then the only one                  */
+  /* independent x / y grids (reference sg.py:103-119: nx != ny).  0 = M.  M is then the LARGER of the two node  */
+  /* counts -- the tiling, LD and every padded array are built for it, tail = 0 --, the operators and vectors of  */
+  /* the shorter axis are zero padded like everything else, and only the launch-per-stage path runs (modes 3 / 4  */
+  /* answer LDC_E_ARG).                                                                                           */
+  int32_t Mx, My;     /* nodes along x (first index) / y (second index)                                           */
 } ldc_problem;
 
 typedef struct ldc_solver ldc_solver;   /* opaque */
@@ -281,6 +286,9 @@ int ldc_poisson_fastdiag(const double *Qx, const double *Qxinv, const double *Qy
 /* out_val[5], out_idx[5] (flat index ix*LD+iy): 0 primary, 1 |omega| max, 2 BR, 3 BL, 4 TL */
 int ldc_vortex_extrema(const double *Psi, const double *W, const double *x, const double *y,
                        int M, int LD, double *out_val, int32_t *out_idx, void *stream);
+/* the same on an Mx x My node grid (nx != ny)                                             */
+int ldc_vortex_extrema_xy(const double *Psi, const double *W, const double *x, const double *y,
+                          int Mx, int My, int LD, double *out_val, int32_t *out_idx, void *stream);
 
 /* Timing experiments.  The switches exist only in the INSTRUMENTED build of the library (csrc/ldc_kernels.hip       */
 /* compiled with -DLDC_TIMING -> lib/libldc_hip_timing.so, loaded by tools/kbench.py, kstamps.py, pstamps.py,          */

@@ -174,8 +174,11 @@ class OracleSG:
 
     def __init__(self, N, Re, *, lid_velocity=1.0, Lx=1.0, Ly=1.0, CFL=1.5, beta_squared=5.0,
                  corner_treatment="smoothing", corner_smoothing=0.15, stage_pressure=False,
-                 basis_type="chebyshev"):
+                 basis_type="chebyshev", ny=None):
+        # (ny: polynomial order of the y grid when it differs from N = nx -- reference sg.py:103-119 builds the two
+        #  grids independently)
         self.N, self.Re = int(N), float(Re)
+        self.Ny = int(N if ny is None else ny)
         self.U, self.Lx, self.Ly = float(lid_velocity), float(Lx), float(Ly)
         self.CFL, self.beta2 = float(CFL), float(beta_squared)
         self.stage_pressure = bool(stage_pressure)
@@ -183,18 +186,19 @@ class OracleSG:
         if kind not in ("chebyshev", "legendre"):                # sg.py:52-63
             raise ValueError(f"Unknown basis_type: {basis_type}. Use 'legendre' or 'chebyshev'")
         self.ax = Axis(self.N, self.Lx, kind)
-        self.ay = Axis(self.N, self.Ly, kind)
-        M = self.N + 1
+        self.ay = Axis(self.Ny, self.Ly, kind)
+        M, My = self.N + 1, self.Ny + 1
         self.M, self.Mi = M, M - 2
+        self.My, self.Myi = My, My - 2
         self.u_lid = lid_profile(self.ax.x, corner_treatment, corner_smoothing, self.U, self.Lx)
         self.W = np.outer(self.ax.w, self.ay.w)                # sg.py:493
-        self.u = np.zeros((M, M))
-        self.v = np.zeros((M, M))
-        self.p = np.zeros((self.Mi, self.Mi))
+        self.u = np.zeros((M, My))
+        self.v = np.zeros((M, My))
+        self.p = np.zeros((self.Mi, self.Myi))
         self.u[:, -1] = self.u_lid                             # sg.py:98, 250-253
-        self.Ru = np.zeros((M, M))
-        self.Rv = np.zeros((M, M))
-        self.Rp = np.zeros((self.Mi, self.Mi))
+        self.Ru = np.zeros((M, My))
+        self.Rv = np.zeros((M, My))
+        self.Rp = np.zeros((self.Mi, self.Myi))
 
     # -- a8: sg.py:387-408
     def timestep(self) -> float:
@@ -304,8 +308,7 @@ class OracleSG:
 
     # -- a16: sg.py:144-179, 451-461 (quirk Q5: linear extrapolation, not the interpolant)
     def pressure_on_full_grid(self):
-        M = self.M
-        f = np.zeros((M, M))
+        f = np.zeros((self.M, self.My))
         f[1:-1, 1:-1] = self.p
         f[0, 1:-1] = 2 * f[1, 1:-1] - f[2, 1:-1]
         f[-1, 1:-1] = 2 * f[-2, 1:-1] - f[-3, 1:-1]
@@ -325,7 +328,7 @@ class OracleSG:
         w = self.vorticity()
         A = self.ax.D2[1:-1, 1:-1]
         B = self.ay.D2[1:-1, 1:-1]
-        psi = np.zeros((self.M, self.M))
+        psi = np.zeros((self.M, self.My))
         psi[1:-1, 1:-1] = solve_sylvester(A, B.T, -w[1:-1, 1:-1])
         return psi
 

@@ -257,6 +257,34 @@ def g4b_variants():
     (OUT / "g4b_variants.json").write_text(json.dumps(meta, indent=1))
 
 
+def g13_unequal_grids():
+    """nx != ny (reference sg.py:103-119 builds the two grids independently; no shipped config uses it): short
+    trajectories from rest with the full set of records, omega, psi and the vortex metrics of the end state."""
+    cases = {
+        "nx24_ny40": dict(nx=24, ny=40, Re=100.0, K=60, kw=dict()),
+        "nx40_ny20": dict(nx=40, ny=20, Re=400.0, K=80, kw=dict(Lx=2.0, Ly=1.0)),
+        "nx17_ny32": dict(nx=17, ny=32, Re=100.0, K=60, kw=dict(corner_treatment="saad")),
+    }
+    out, meta = {}, {}
+    for name, c in cases.items():
+        s = make_sg(c["nx"], c["Re"], ny=c["ny"], **c["kw"])
+        h = _run_steps(s, c["K"])
+        out[f"{name}_u"] = s.arrays.u.copy()
+        out[f"{name}_v"] = s.arrays.v.copy()
+        out[f"{name}_p"] = s.arrays.p.copy()
+        out[f"{name}_omega"] = s._compute_vorticity()
+        psi, _, _ = s._compute_streamfunction()
+        out[f"{name}_psi"] = psi
+        vm = s.compute_vortex_metrics()
+        meta[name] = dict(nx=c["nx"], ny=c["ny"], Re=c["Re"], K=c["K"], kw=c["kw"],
+                          vortex={k: float(v) for k, v in vm.items()})
+        for k, val in h.items():
+            out[f"{name}_{k}"] = val
+        print(f"  {name}: u {s.arrays.u.shape}, p {s.arrays.p.shape}, psi {np.shape(psi)}")
+    np.savez_compressed(OUT / "g13_unequal_grids.npz", **out)
+    (OUT / "g13_unequal_grids.json").write_text(json.dumps(meta, indent=1))
+
+
 def g7_converged(N=32, Re=100.0):
     """Full solve() at (N, Re), tol 1e-6 through the reference's own loop (a13, a16)."""
     t0 = time.time()
@@ -405,7 +433,7 @@ def g8_fsg(full=False):
 
 GROUPS = {
     "G1": g1_operators, "G2": g2_lid, "G3": g3_single_stage, "G4": g4_trajectories,
-    "G4b": g4b_variants, "G7": g7_converged, "G7b": g7b_converged_n64, "G11": g11_interp, "G8": g8_fsg, "G12": g12_legendre,
+    "G4b": g4b_variants, "G7": g7_converged, "G7b": g7b_converged_n64, "G11": g11_interp, "G8": g8_fsg, "G12": g12_legendre, "G13": g13_unequal_grids,
 }
 
 

@@ -56,8 +56,8 @@ def test_python_constants_match_the_header(lib):
 
 
 def test_struct_size_matches_header(lib):
-    # 4 int32 + 7 double + 4 int32 + (37 + 27 packed twins) ptr + int64 + 4 ptr (scal, ctrl, rec, sync)
-    assert C.sizeof(lib.Problem) == 16 + 56 + 16 + (37 + 27) * 8 + 8 + 32
+    # 4 int32 + 7 double + 4 int32 + (37 + 27 packed twins) ptr + int64 + 4 ptr (scal, ctrl, rec, sync) + 2 int32 (Mx, My)
+    assert C.sizeof(lib.Problem) == 16 + 56 + 16 + (37 + 27) * 8 + 8 + 32 + 8
 
 
 def test_argument_validation_needs_no_device(lib):
