@@ -344,10 +344,10 @@ def main(argv=None) -> float | None:
         share = {}
         for q, c in enumerate(cfgs):
             sv = c["solver"]
-            share.setdefault((sv["_target_"], int(c["N"]), int(sv.get("n_levels", 0)), bool(sv.get("diagnostics", True))),
-                             []).append(q)
+            share.setdefault((sv["_target_"], int(c["N"]), int(sv.get("n_levels", 0)), bool(sv.get("diagnostics", True)),
+                              int(sv.get("nx", c["N"])), int(sv.get("ny", c["N"]))), []).append(q)      # (nx, ny: solver.ny=... overrides)
         groups, where = [], []
-        for (target, _, _, _), members in share.items():
+        for (target, _, _, _, _, _), members in share.items():
             if target in (SG, FSG) and len(members) > 1 and max_batch > 1:
                 # sizes the trial-per-CU kernel holds (M <= 44): one work-group per trial, 256 advance at once -- a larger
                 # batch is a better batch there (unless LDC_MAX_BATCH / hydra.launcher.batch_trials says otherwise)
