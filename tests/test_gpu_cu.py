@@ -236,3 +236,29 @@ def test_batches_pick_the_kernel_by_their_size():
         assert np.max(np.abs(b.solvers[q].arrays.u.reshape(N + 1, N + 1) - o.u)) < 1e-12
         assert rel(recs[q][:, 7], ref[:, 7]) < 1e-12 and rel(recs[q][:, 4], ref[:, 4]) < 1e-10
         b.close()
+
+
+def test_cu_batch_with_diverging_trials_latches_each_one_where_it_blows_up():
+    """N = 16 at Re = 1000 blows up after ~2 300 iterations (the reference's scheme does: the oracle too).  In a batch large
+    enough for the trial-per-CU kernel every work-group closes its own iterations: the NaN latch fires per trial, at the
+    iteration the same trial alone reaches it, while the stable trials of the batch run on."""
+    from solvers.spectral import ldc_lib as L
+    from solvers.spectral.batched import BatchedSGSolver
+    from solvers.spectral.sg import SGSolver
+    B = L.CU_AUTO_TRIALS + 2
+    kw = dict(name="spectral", lid_velocity=1.0, Lx=1.0, Ly=1.0, nx=16, ny=16, tolerance=1e-12, max_iterations=6000,
+              basis_type="chebyshev", CFL=1.5, beta_squared=5.0, corner_treatment="smoothing", multigrid="none",
+              check_every=1024, graph_iters=16, nan_guard=True)
+    trials = [dict(kw, Re=1000.0 if q % 2 else 100.0, corner_smoothing=0.02 + 0.001 * q) for q in range(B)]
+    b = BatchedSGSolver(trials)
+    ms = b.solve()
+    assert L.lib().ldc_batch_mode(b._batch) == 4
+    its = [m.iterations for m in ms]
+    assert all(its[q] == 6000 for q in range(0, B, 2))                       # the stable ones reach the cap
+    assert all(500 < its[q] < 6000 and not ms[q].converged for q in range(1, B, 2))
+    for q in (1, B - 1 if (B - 1) % 2 else B - 2):
+        one = SGSolver(**dict(trials[q], persistent=4))
+        one.solve()
+        assert one.metrics.iterations == its[q], q
+        one.close()
+    b.close()
