@@ -141,7 +141,8 @@ def run_batches(groups: list, device: str = None) -> list:
     tasks.sort(key=lambda t: (-t[0], t[1], t[2]))
     n_tasks = len(tasks)
     n_threads = max(1, min(n_workers, n_tasks))
-    lock, done = threading.Lock(), {}
+    lock, done, early = threading.Lock(), {}, {}
+    t0 = time.perf_counter()
 
     def worker(_):
         while True:
@@ -167,11 +168,17 @@ def run_batches(groups: list, device: str = None) -> list:
                     batch = (BatchedFSGSolver if fsg else BatchedSGSolver)(nodes)     # built on this worker's stream
                 batch.solve()
                 done[(gi, lo)] = batch
+                # The records of this batch (validation, Ghia error, results.json, solution.vts: host work on the trials'
+                # own fields, ~45 ms each) right away, on this worker: the other workers' batches keep the GPU busy
+                # meanwhile.  (300 records made after the last batch of a round were 13 s of a 34-s round.)  With MLflow
+                # active they are made afterwards, in the caller's thread and in order (its fluent API keeps ONE active run).
+                if _mlflow() is None:
+                    cfgs_g, dirs_g = groups[gi]
+                    early[(gi, lo)] = [make_record(cfgs_g[lo + q], s, dirs_g[lo + q], t0) for q, s in enumerate(batch.solvers)]
             except Exception as exc:                # the other batches go on; the farm reports the failure
                 log.exception("batch of %d trials at N=%s failed", len(part), part[0]["N"])
                 done[(gi, lo)] = exc
 
-    t0 = time.perf_counter()
     wall = run_concurrently(list(range(n_threads)), worker, device)
     good = [b for b in done.values() if not isinstance(b, Exception)]
     busy = sum(b.batch_seconds for b in good)
@@ -184,12 +191,20 @@ def run_batches(groups: list, device: str = None) -> list:
                 recs += [dict(error=repr(batch), objective=math.inf) for _ in range(lo, hi)]
                 continue
             for q, s in enumerate(batch.solvers):
-                if n_threads > 1 and busy > 0:      # the shares of all trials add up to the pool's wall time
-                    s.metrics.wall_time_seconds *= wall / busy
-                r = make_record(cfgs[lo + q], s, dirs[lo + q], t0)
+                scale = wall / busy if (n_threads > 1 and busy > 0) else 1.0      # the shares of all trials add up to the pool's wall time
+                s.metrics.wall_time_seconds *= scale
+                if (gi, lo) in early:               # made on the worker: bring the wall-time share up to date
+                    r = early[(gi, lo)][q]
+                    r["metrics"] = s.metrics.to_mlflow()
+                    m = s.metrics
+                    r["steps_per_second"] = m.iterations / m.wall_time_seconds if m.wall_time_seconds > 0 else 0.0
+                else:
+                    r = make_record(cfgs[lo + q], s, dirs[lo + q], t0)
                 # the batch's own wall time (batches of other streams ran beside it) and the pool's
                 r["solve_batch_seconds"], r["solve_batch_size"] = batch.batch_seconds, len(batch)
                 r["solve_pool_seconds"], r["solve_streams"], r["solve_group_size"] = wall, n_threads, len(cfgs)
+                if (gi, lo) in early:
+                    (dirs[lo + q] / "results.json").write_text(json.dumps(_jsonable(r), indent=1))
                 recs.append(r)
             batch.close()
         out.append(recs)
