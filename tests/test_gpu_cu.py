@@ -262,3 +262,24 @@ def test_cu_batch_with_diverging_trials_latches_each_one_where_it_blows_up():
         assert one.metrics.iterations == its[q], q
         one.close()
     b.close()
+
+
+def test_every_small_size_through_both_small_kernels():
+    """N = 4 ... 43, every size once through the trial-per-CU kernel and once through the small-N kernel (12 iterations with
+    E/Z/P against the oracle): no size between the parametrised ones hides an indexing case of its own."""
+    from solvers.spectral import ldc_lib as L
+    K = 12
+    for N in range(4, 44):
+        o = orc.OracleSG(N, 100.0)
+        want = oracle_rows(o, K)
+        for mode in (4, 3):
+            s = make(N, 100.0, persistent=mode, check_every=64)
+            rec = s.run_iterations(K)
+            assert L.lib().ldc_solver_mode(s._handle) == mode, (N, mode)
+            M = N + 1
+            assert np.max(np.abs(s.arrays.u.reshape(M, M) - o.u)) < 1e-12, (N, mode)
+            assert np.max(np.abs(s.arrays.p.reshape(M - 2, M - 2) - o.p)) < 1e-12, (N, mode)
+            assert rel(rec[:, 7], want[:, 7]) < 1e-12, (N, mode)
+            for c in range(1, 7):
+                assert rel(rec[:, c], want[:, c]) < (1e-10 if c < 5 else 1e-9), (N, mode, c)
+            s.close()
