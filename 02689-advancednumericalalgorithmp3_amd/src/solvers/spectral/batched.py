@@ -231,6 +231,35 @@ class BatchedFSGSolver:
         for s in self.solvers:
             s.close()
 
+    def _run_level(self, group, tols, caps):
+        """One level of all trials that are still alive.  A level the small kernels advance is ONE launch per chunk with every
+        trial on an XCD / a CU of its own; a level on the launch path (N >= 80: the fine level of BASELINE config 5) gains what
+        any launch-path batch gains from two halves on two streams (solve_concurrently: up to 1.3x) -- the coarse level of
+        the same solve decides that the whole solve is one batch (main.py: run_batches), so the split happens here."""
+        import os
+        batch = BatchedSGSolver.from_solvers(group)
+        n = len(group)
+        split = n >= 4 and int(os.environ.get("LDC_BATCH_STREAMS", "3")) >= 2
+        if split:
+            batch._ensure_batch(list(tols))
+            split = L.lib().ldc_batch_mode(batch._batch) == 0
+        if not split:
+            out = batch.run_to_tolerance(tols, caps, diagnostics=False)
+            batch.close_batch()
+            return out
+        batch.close_batch()
+        h = n // 2
+        parts = [(group[:h], tols[:h], caps[:h]), (group[h:], tols[h:], caps[h:])]
+        outs = [None, None]
+
+        def run(k):
+            b = BatchedSGSolver.from_solvers(parts[k][0])
+            outs[k] = b.run_to_tolerance(parts[k][1], parts[k][2], diagnostics=False)
+            b.close_batch()
+
+        run_concurrently([0, 1], run, group[0].device, first_stream=8)      # (streams of their own: not the pool's)
+        return outs[0] + outs[1]
+
     def solve(self, max_iter: int = None):
         t0 = time.perf_counter()
         fines = self.solvers
@@ -253,9 +282,7 @@ class BatchedFSGSolver:
             tols = [fines[q].params.tolerance * fines[q].params.coarse_tolerance_factor ** (nlev - 1 - idx)
                     for q in alive]
             caps = [fines[q].params.max_iterations if max_iter is None else max_iter for q in alive]
-            batch = BatchedSGSolver.from_solvers(group)
-            out = batch.run_to_tolerance(tols, caps, diagnostics=False)
-            batch.close_batch()
+            out = self._run_level(group, tols, caps)
             nxt = []
             for q, (done, its, _) in zip(alive, out):
                 total[q] += its
@@ -279,7 +306,7 @@ class BatchedFSGSolver:
 _WORKER_STREAMS = {}      # (device index, worker) -> torch.cuda.Stream, see run_concurrently
 
 
-def run_concurrently(batches: list, fn, device=None) -> float:
+def run_concurrently(batches: list, fn, device=None, first_stream: int = 0) -> float:
     """``fn(batch)`` for every batch object AT THE SAME TIME, one host thread and one HIP stream each; returns the
     wall time of the lot.  The streams alternate between the two stream priorities HIP offers: streams of different
     priority never share a hardware queue, while which streams of ONE priority do is the runtime's choice (and on a
@@ -303,7 +330,7 @@ def run_concurrently(batches: list, fn, device=None) -> float:
     # which hardware queue a new stream lands on is the runtime's business, the first pair's placement is the measured one
     streams = []
     for k in range(len(batches)):
-        key = (dev.index, k)
+        key = (dev.index, first_stream + k)      # (first_stream: a nested use -- the levels of a batched FSG solve -- keeps off the pool's)
         if key not in _WORKER_STREAMS:
             with torch.cuda.device(dev):
                 least, greatest = C.c_int(), C.c_int()
