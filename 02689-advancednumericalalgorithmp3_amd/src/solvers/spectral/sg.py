@@ -36,6 +36,46 @@ _PACKED_STATE = ("U", "UT", "V", "VT", "P", "UA", "UAT", "VA", "VAT", "PA", "UB"
 _DEBUG_KEYS = ("du_dx", "du_dy", "dv_dx", "dv_dy", "lap_u", "lap_v", "dp_dx", "dp_dy", "R_u", "R_v", "R_p")
 
 
+_EIG_CACHE = {}
+_AXIS_CACHE = {}
+
+
+def _axis_operators(basis, kind: str, M: int):
+    """(nodes, D, D^2, inner-to-full interpolation, quadrature weights) of one axis.  Kept per (basis, domain, M) and handed out
+    read-only: the trials of a sweep differ in Re and in the lid, not in their grids, and building these was ~50 ms per solver."""
+    key = (str(kind).lower(), tuple(float(v) for v in basis.domain), int(M))
+    hit = _AXIS_CACHE.get(key)
+    if hit is None:
+        x = basis.nodes(M)
+        D = basis.diff_matrix(x)
+        hit = (x, D, D @ D, inner_to_full_interpolation(x[1:-1], x), basis.quadrature_weights(M))
+        for a in hit:
+            a.setflags(write=False)
+        if len(_AXIS_CACHE) > 64:
+            _AXIS_CACHE.clear()
+        _AXIS_CACHE[key] = hit
+    return hit
+
+
+def _interior_eigenbasis(D2: np.ndarray):
+    """(lam, Q, Q^-1) of the interior block of a second-derivative matrix.  Kept per matrix (its bytes): the trials of a sweep
+    share their operators, and the two decompositions were ~0.1 s of host time per trial at N=128."""
+    import hashlib
+    blk = np.ascontiguousarray(D2[1:-1, 1:-1])
+    key = (blk.shape, hashlib.sha1(blk.tobytes()).hexdigest())
+    hit = _EIG_CACHE.get(key)          # (worker threads of a sweep share the cache: read once, never re-read after a clear)
+    if hit is None:
+        lam, Q = np.linalg.eig(blk)
+        if np.max(np.abs(lam.imag)) > 1e-8 * np.max(np.abs(lam.real)):
+            raise RuntimeError("interior D2 block has complex eigenvalues")
+        lam, Q = lam.real, Q.real
+        hit = (lam, Q, np.linalg.inv(Q))
+        if len(_EIG_CACHE) > 32:
+            _EIG_CACHE.clear()
+        _EIG_CACHE[key] = hit
+    return hit
+
+
 class _ArraysView:
     """``solver.arrays.u / .v / .p`` as host copies of the device state (flat, like the
     reference's SpectralSolverFields); assigning uploads."""
@@ -106,20 +146,12 @@ class SGSolver(LidDrivenCavitySolver):
         Mx, My = p.nx + 1, p.ny + 1
         M = max(Mx, My)
         self.M, self.Mx, self.My = M, Mx, My
-        x = self.basis_x.nodes(Mx)
-        y = self.basis_y.nodes(My)
+        x, self.Dx_1d, self.Dxx_1d, self.Interp_x, self.w_x = _axis_operators(self.basis_x, p.basis_type, Mx)
+        y, self.Dy_1d, self.Dyy_1d, self.Interp_y, self.w_y = _axis_operators(self.basis_y, p.basis_type, My)
         self.x_nodes, self.y_nodes = x, y
         self.x_full, self.y_full = np.meshgrid(x, y, indexing="ij")
         self.dx_min = float(np.min(np.diff(x)))
         self.dy_min = float(np.min(np.diff(y)))
-        self.Dx_1d = self.basis_x.diff_matrix(x)
-        self.Dy_1d = self.basis_y.diff_matrix(y)
-        self.Dxx_1d = self.Dx_1d @ self.Dx_1d
-        self.Dyy_1d = self.Dy_1d @ self.Dy_1d
-        self.Interp_x = inner_to_full_interpolation(x[1:-1], x)
-        self.Interp_y = inner_to_full_interpolation(y[1:-1], y)
-        self.w_x = self.basis_x.quadrature_weights(Mx)
-        self.w_y = self.basis_y.quadrature_weights(My)
         u_lid, _ = self.corner_treatment.get_lid_velocity(
             x, np.full_like(x, p.Ly), lid_velocity=p.lid_velocity, Lx=p.Lx, Ly=p.Ly)
         self.u_lid = u_lid
@@ -472,11 +504,7 @@ class SGSolver(LidDrivenCavitySolver):
             import torch
             out = {}
             for tag, D2 in (("x", self.Dxx_1d), ("y", self.Dyy_1d)):
-                lam, Q = np.linalg.eig(D2[1:-1, 1:-1])
-                if np.max(np.abs(lam.imag)) > 1e-8 * np.max(np.abs(lam.real)):
-                    raise RuntimeError("interior D2 block has complex eigenvalues")
-                lam, Q = lam.real, Q.real
-                out[tag] = (lam, Q, np.linalg.inv(Q))
+                out[tag] = _interior_eigenbasis(D2)
             names = {"Qx": out["x"][1], "Qxi": out["x"][2], "Qy": out["y"][1], "Qyi": out["y"][2]}
             self._eig_t = torch.zeros((4, self.LD, self.LD), dtype=torch.float64, device=self.device)
             for k, (n, a) in enumerate(names.items()):
