@@ -174,7 +174,10 @@ def run_batches(groups: list, device: str = None) -> list:
                 # active they are made afterwards, in the caller's thread and in order (its fluent API keeps ONE active run).
                 if _mlflow() is None:
                     cfgs_g, dirs_g = groups[gi]
-                    early[(gi, lo)] = [make_record(cfgs_g[lo + q], s, dirs_g[lo + q], t0) for q, s in enumerate(batch.solvers)]
+                    try:
+                        early[(gi, lo)] = [make_record(cfgs_g[lo + q], s, dirs_g[lo + q], t0) for q, s in enumerate(batch.solvers)]
+                    except Exception:                # the solve stands; its records are tried again, one by one, afterwards
+                        log.exception("records of a batch of %d trials at N=%s failed on the worker", len(part), part[0]["N"])
             except Exception as exc:                # the other batches go on; the farm reports the failure
                 log.exception("batch of %d trials at N=%s failed", len(part), part[0]["N"])
                 done[(gi, lo)] = exc
