@@ -283,3 +283,32 @@ def test_every_small_size_through_both_small_kernels():
             for c in range(1, 7):
                 assert rel(rec[:, c], want[:, c]) < (1e-10 if c < 5 else 1e-9), (N, mode, c)
             s.close()
+
+
+def test_cu_variants_and_legendre_vs_reference(golden_dir):
+    """The reference's short runs with non-default parameters (Saad lid, other CFL / beta^2, Lx != Ly with another lid speed,
+    odd N: g4b) and with the Legendre basis (g12: both EDGE sizes, 17 and 33 nodes) through the trial-per-CU kernel."""
+    g = np.load(golden_dir / "g4b_variants.npz")
+    meta = json.loads((golden_dir / "g4b_variants.json").read_text())
+    for name, c in meta.items():
+        s = make(c["N"], c["Re"], **c["kw"])
+        rec = s.run_iterations(c["K"])
+        assert mode_of(s) == 4, name
+        for k, a in (("u", s.arrays.u), ("v", s.arrays.v), ("p", s.arrays.p)):
+            assert np.max(np.abs(a - g[f"{name}_{k}"])) < 1e-12, (name, k)
+        assert rel(rec[:, 7], g[f"{name}_dt"]) < 1e-12, name
+        assert rel(rec[:, 1:4], g[f"{name}_res"]) < 1e-10, name
+        assert rel(rec[:, 6], g[f"{name}_P"]) < 1e-9, name
+        s.close()
+    g = np.load(golden_dir / "g12_legendre.npz")
+    meta = json.loads((golden_dir / "g12_legendre.json").read_text())
+    for tag, c in meta.items():
+        s = make(c["N"], c["Re"], basis_type="legendre")
+        rec = s.run_iterations(c["K"])
+        assert mode_of(s) == 4, tag
+        for k, a in (("u", s.arrays.u), ("v", s.arrays.v), ("p", s.arrays.p)):
+            assert np.max(np.abs(a - g[f"{tag}_{k}"])) < 1e-11, (tag, k)
+        assert rel(rec[:, 7], g[f"{tag}_dt"]) < 1e-12 and rel(rec[:, 1:4], g[f"{tag}_res"]) < 1e-10
+        for col, k in ((4, "E"), (5, "Z"), (6, "P")):
+            assert rel(rec[:, col], g[f"{tag}_{k}"]) < 1e-9, (tag, k)
+        s.close()
