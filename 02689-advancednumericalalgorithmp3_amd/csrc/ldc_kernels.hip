@@ -2000,14 +2000,13 @@ int persistent_mode(const ldc_solver* s) {
 bool use_persistent(const ldc_solver* s) { const int m = persistent_mode(s); return m == 1 || m == 2; }
 
 // ---- small-N trial kernel (mode 3) -----------------------------------------------------------------------------
-constexpr size_t kXcdLdsBytes = XLds::BYTES;
-static_assert(kXcdLdsBytes <= kLdsLimit - 1024, "small-N trial kernel LDS (plus its static words)");
+static_assert(XLds::BYTES_NST <= kLdsLimit - 1024, "small-N trial kernel LDS (plus its static words)");
 template <int T>
 int enable_xcd_lds_t() {
   const void* k[3] = {reinterpret_cast<const void*>(xcd_kernel<T, false, false>), reinterpret_cast<const void*>(xcd_kernel<T, false, true>),
                       reinterpret_cast<const void*>(xcd_kernel<T, true, false>)};
   for (const void* f : k) {
-    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXcdLdsBytes);
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXLdsBytes<T>);
     if (e != hipSuccess) return (int)e;
   }
   return 0;
@@ -2057,18 +2056,18 @@ XArgs make_xargs(const ldc_solver* s, int with_diag, unsigned* sync) {
 }
 
 template <typename K>
-int xcd_launch_kernel(K kern, const XLaunch& xl, int nwg, int n_xcds, hipStream_t st) {
+int xcd_launch_kernel(K kern, const XLaunch& xl, int nwg, int n_xcds, hipStream_t st, size_t lds_bytes) {
   // work-groups are dealt round-robin over the XCDs: (slots x tiles + 8) per XCD put at least slots x tiles of them on
   // every XCD; the surplus leaves at once
   const int per_xcd = ((xl.B + n_xcds - 1) / n_xcds) * nwg + 8;
-  hipLaunchKernelGGL(kern, dim3(n_xcds * per_xcd), dim3(kStageThreads), kXcdLdsBytes, st, xl);
+  hipLaunchKernelGGL(kern, dim3(n_xcds * per_xcd), dim3(kStageThreads), lds_bytes, st, xl);
   return (int)hipGetLastError();
 }
 template <int T>
 int xcd_launch_t(const XLaunch& xl, bool sp, bool diag, int n_xcds, hipStream_t st) {
-  if (sp) return xcd_launch_kernel(xcd_kernel<T, true, false>, xl, T * T, n_xcds, st);
-  if (diag) return xcd_launch_kernel(xcd_kernel<T, false, true>, xl, T * T, n_xcds, st);
-  return xcd_launch_kernel(xcd_kernel<T, false, false>, xl, T * T, n_xcds, st);
+  if (sp) return xcd_launch_kernel(xcd_kernel<T, true, false>, xl, T * T, n_xcds, st, kXLdsBytes<T>);
+  if (diag) return xcd_launch_kernel(xcd_kernel<T, false, true>, xl, T * T, n_xcds, st, kXLdsBytes<T>);
+  return xcd_launch_kernel(xcd_kernel<T, false, false>, xl, T * T, n_xcds, st, kXLdsBytes<T>);
 }
 int xcd_launch_any(const XLaunch& xl, bool sp, bool diag, int T, int n_xcds, hipStream_t st) {
   switch (T) {
