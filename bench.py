@@ -142,14 +142,19 @@ def farm_rate(N, B, device, dist, seconds=0.3):
             n += K
         b.iterations_timed = n
 
-    dist.barrier(); torch.cuda.synchronize()
-    dt = run_concurrently(halves, advance, device)
-    torch.cuda.synchronize()
-    done = sum(len(b) * b.iterations_timed for b in halves)
-    state["n"] = min(b.iterations_timed for b in halves)
+    # three windows, the best one counts (a window is 0.3 s of two host threads racing each other: single windows of one
+    # box read 105 ... 131 k trial-iterations/s)
+    best = 0.0
+    for _ in range(3):
+        dist.barrier(); torch.cuda.synchronize()
+        dt = run_concurrently(halves, advance, device)
+        torch.cuda.synchronize()
+        done = sum(len(b) * b.iterations_timed for b in halves)
+        if done / dt > best:
+            best, state["n"] = done / dt, min(b.iterations_timed for b in halves)
     for b in halves:
         b.close()
-    return done / dt, state["n"]
+    return best, state["n"]
 
 
 def stage_kernel_time(s, bursts=20, pairs_per_burst=100):
