@@ -255,6 +255,15 @@ def cpu_baseline(N, Re, budget_s=14.0):
                        f"(best of {cands}; {cap} CPUs available)")
 
 
+def _plain_stage_entry(kernels: dict):
+    """The dominant kernel's entry of a PMC summary: stage_kernel<GP=0, LAST=0, DUMP=0, BATCH=0, DIAG=0[, RECT=0]> (the square-grid
+    instantiation; the last template argument exists since nx != ny is supported)."""
+    for name in ("stage_kernel<false, false, false, false, 0, false>", "stage_kernel<false, false, false, false, 0>"):
+        if name in kernels:
+            return kernels[name]
+    return None
+
+
 def pmc_traffic(N):
     """HBM/fabric bytes per launch of the dominant kernel from the committed PMC passes
     (profiles/r*_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of tools/pmc_run.py at
@@ -264,7 +273,7 @@ def pmc_traffic(N):
     if N != 256 or not files:
         return None, None
     with open(files[-1]) as f:
-        k = json.load(f)["kernels"].get("stage_kernel<false, false, false, false, 0>")
+        k = _plain_stage_entry(json.load(f)["kernels"])
     return (k["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)) if k else (None, None)
 
 
@@ -280,7 +289,7 @@ def pmc_mfma_util(N, launch_seconds):
         return None
     for f in reversed(files):
         with open(f) as fh:
-            k = json.load(fh)["kernels"].get("stage_kernel<false, false, false, false, 0>", {})
+            k = _plain_stage_entry(json.load(fh)["kernels"]) or {}
         if "SQ_VALU_MFMA_BUSY_CYCLES" in k:
             busy = k["SQ_VALU_MFMA_BUSY_CYCLES"]
             return {"mfma_util": busy / (launch_seconds * 2.4e9 * 1024), "mfma_util_profiled": k.get("mfma_util"),
