@@ -24,9 +24,9 @@ PERSIST_AUTO_XCD_TILES = 0  # LDC_PERSIST_AUTO_XCD_TILES: auto mode picks mode 2
 XCD_TILES = 25              # LDC_XCD_TILES: mode 3 (the small-N trial kernel) runs trials of up to ceil(M/16)^2 = 25 tiles
 XCD_AUTO_TILES = 25         # LDC_XCD_AUTO_TILES: auto mode picks mode 3 up to here
 CU_MAX_M = 44                # LDC_CU_MAX_M: the trial-per-CU kernel (mode 4) holds the stage state of M <= 44 in one CU's LDS
-CU_AUTO_TRIALS = 128         # LDC_CU_AUTO_TRIALS: batches of at least this many trials take mode 4 by themselves (ceil(M/16) <= 2)
+CU_AUTO_TRIALS = 80          # LDC_CU_AUTO_TRIALS: batches of at least this many trials take mode 4 by themselves (ceil(M/16) <= 2)
 CU_AUTO_TRIALS_T3 = 80       # LDC_CU_AUTO_TRIALS_T3: the same for ceil(M/16) == 3
-CU_AUTO_TRIALS_M33 = 40      # LDC_CU_AUTO_TRIALS_M33: the same for M == 33 (N = 32)
+CU_AUTO_TRIALS_M33 = 32      # LDC_CU_AUTO_TRIALS_M33: the same for M == 33 (N = 32)
 REC_REL, REC_RU, REC_RV, REC_RP, REC_E, REC_Z, REC_P, REC_DT = range(8)
 CTRL_DONE, CTRL_ITER = 0, 1
 SCAL_DT, SCAL_UMAX, SCAL_VMAX = 0, 1, 2

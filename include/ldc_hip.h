@@ -230,10 +230,10 @@ int ldc_solver_set_graph_iters(ldc_solver *s, int iters_per_graph);
 #define LDC_CU_MAX_M 44
 /* (measured, profiles/r03_cu_ab.log: the trial-per-CU kernel scales with the number of trials up to 256, the small-N kernel    */
 /*  saturates where its XCDs are full -- 64 trials at ceil(M/16) <= 2 (5.7 M trial-iterations/s), 8 ... 24 above (1.9 M); the    */
-/*  thresholds are where the two lines cross)                                                                                     */
-#define LDC_CU_AUTO_TRIALS 128       /* ceil(M/16) <= 2                                                  */
+/*  thresholds are where the two lines cross: profiles/r03_cu_ab_thresholds.log)                                                                                     */
+#define LDC_CU_AUTO_TRIALS 80        /* ceil(M/16) <= 2                                                  */
 #define LDC_CU_AUTO_TRIALS_T3 80     /* ceil(M/16) == 3                                                  */
-#define LDC_CU_AUTO_TRIALS_M33 40    /* M == 33 (N = 32): four tile waves + two edge waves instead of nine tile waves */
+#define LDC_CU_AUTO_TRIALS_M33 32    /* M == 33 (N = 32): four tile waves + two edge waves instead of nine tile waves */
 int ldc_solver_set_persistent(ldc_solver *s, int mode);
 /* the mode ldc_solver_enqueue will really use for more than one iteration (0, 1, 2, 3 or 4): what set_persistent asked   */
 /* for, resolved against what the handle's size and device allow.  A host that drives several streams uses it to keep  */
