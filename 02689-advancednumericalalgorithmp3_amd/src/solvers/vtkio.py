@@ -102,7 +102,8 @@ class StructuredGridFile:
 
         def enc(a, typ="Float64"):
             raw = np.ascontiguousarray(a, dtype=_NP[typ]).tobytes()
-            comp = zlib.compress(raw, 1)      # (fp64 fields barely compress: level 1 is a third of the default's time, 27 -> 9 ms at N=128)
+            comp = zlib.compress(raw, 0)      # (a valid zlib stream, stored: fp64 fields barely compress, and deflating the nine arrays
+                                              #  of an N=128 trial was 62 ms of its 115-ms record even at level 1)
             head = struct.pack("<IIII", 1, len(raw), len(raw), len(comp))
             return (base64.b64encode(head) + base64.b64encode(comp)).decode()
 
