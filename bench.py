@@ -427,7 +427,7 @@ def main():
     barrier()
     g._paths()
 
-    gi = graph_iters_for(a.steps)
+    gi = int(os.environ.get("LDC_BENCH_GRAPH_ITERS", graph_iters_for(a.steps)))       # (the override is for experiments)
     s = make_solver(a.N, a.Re, f"cuda:{local}", graph_iters=gi, persistent=a.persistent)
     s._begin(0.0)
     from solvers.spectral import ldc_lib as L
