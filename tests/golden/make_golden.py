@@ -235,6 +235,38 @@ def g4_trajectories(full=False):
         print(f"  traj N={N} Re={Re} K={K}: {time.time() - t0:.1f}s")
 
 
+def _compact_state(a, name, out):
+    """A 2-D array in compact form: six rows and six columns (first two, quarter, middle, last two), the lattice of
+    every 8th node, the 2-norm and the maximum -- a few KB that pin every node class of a large grid."""
+    n0, n1 = a.shape
+    rows = sorted({0, 1, n0 // 4, n0 // 2, n0 - 2, n0 - 1})
+    cols = sorted({0, 1, n1 // 4, n1 // 2, n1 - 2, n1 - 1})
+    out[f"{name}_rows_idx"] = np.array(rows)
+    out[f"{name}_cols_idx"] = np.array(cols)
+    out[f"{name}_rows"] = a[rows, :].copy()
+    out[f"{name}_cols"] = a[:, cols].copy()
+    out[f"{name}_lattice"] = a[::8, ::8].copy()
+    out[f"{name}_norm2"] = np.array(np.linalg.norm(a))
+    out[f"{name}_max"] = np.array(np.max(np.abs(a)))
+
+
+def g4c_headline_sizes():
+    """The reference itself at the two large BASELINE geometries (configs 3-5): K steps from rest at (N=128, Re=1000, K=40)
+    and (N=256, Re=1000, K=25), and ten / eight times as long (K=400, K=200) -- every record in full, the end state in compact form (_compact_state)."""
+    for N, Re, K in ((128, 1000.0, 40), (256, 1000.0, 25), (128, 1000.0, 400), (256, 1000.0, 200)):
+        t0 = time.time()
+        s = make_sg(N, Re)
+        h = _run_steps(s, K)
+        M = N + 1
+        out = dict(**h)
+        _compact_state(s.arrays.u.reshape(M, M), "u", out)
+        _compact_state(s.arrays.v.reshape(M, M), "v", out)
+        _compact_state(s.arrays.p.reshape(M - 2, M - 2), "p", out)
+        _compact_state(np.asarray(s._compute_vorticity()).reshape(M, M), "omega", out)
+        np.savez_compressed(OUT / f"g4c_traj_N{N}_Re{int(Re)}_K{K}.npz", **out)
+        print(f"  traj N={N} Re={Re} K={K}: {time.time() - t0:.1f}s")
+
+
 def g4b_variants():
     """Short trajectories with non-default parameters (Saad lid, other CFL/beta, Lx!=Ly)."""
     cases = {
@@ -433,7 +465,7 @@ def g8_fsg(full=False):
 
 GROUPS = {
     "G1": g1_operators, "G2": g2_lid, "G3": g3_single_stage, "G4": g4_trajectories,
-    "G4b": g4b_variants, "G7": g7_converged, "G7b": g7b_converged_n64, "G11": g11_interp, "G8": g8_fsg, "G12": g12_legendre, "G13": g13_unequal_grids,
+    "G4b": g4b_variants, "G4c": g4c_headline_sizes, "G7": g7_converged, "G7b": g7b_converged_n64, "G11": g11_interp, "G8": g8_fsg, "G12": g12_legendre, "G13": g13_unequal_grids,
 }
 
 

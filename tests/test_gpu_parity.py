@@ -121,6 +121,46 @@ def test_trajectory_vs_reference(golden_dir, N, Re, K):
         assert abs(vm[str(key)] - ref) <= 1e-9 * max(abs(ref), 1.0), key
 
 
+def compact_diffs(a, g, name):
+    """Largest deviations of a 2-D array from the compact form a G4c fixture holds (make_golden._compact_state)."""
+    rows, cols = g[f"{name}_rows_idx"], g[f"{name}_cols_idx"]
+    d = max(np.max(np.abs(a[rows, :] - g[f"{name}_rows"])), np.max(np.abs(a[:, cols] - g[f"{name}_cols"])),
+            np.max(np.abs(a[::8, ::8] - g[f"{name}_lattice"])))
+    dn = abs(np.linalg.norm(a) - float(g[f"{name}_norm2"])) / max(float(g[f"{name}_norm2"]), 1e-300)
+    dm = abs(np.max(np.abs(a)) - float(g[f"{name}_max"]))
+    return d, dn, dm
+
+
+def check_g4c(g, s, rec, N):
+    """A solver's state and records against a G4c fixture (the reference's own run at N = 128 / 256)."""
+    M = N + 1
+    for name, a in (("u", s.arrays.u.reshape(M, M)), ("v", s.arrays.v.reshape(M, M)), ("p", s.arrays.p.reshape(M - 2, M - 2))):
+        d, dn, dm = compact_diffs(a, g, name)
+        assert d < 1e-12 and dn < 1e-12 and dm < 1e-12, (name, d, dn, dm)
+    d, dn, _ = compact_diffs(np.asarray(s._compute_vorticity()).reshape(M, M), g, "omega")
+    assert d < 1e-10 * float(g["omega_max"]) and dn < 1e-10, (d, dn)
+    assert rel(rec[:, 7], g["dt"]) < 1e-12
+    assert np.max(np.abs(rec[:, 0] - g["rel"]) / (np.abs(g["rel"]) + 1e-9)) < 1e-8
+    assert rel(rec[:, 1:4], g["res"]) < 1e-10
+    assert rel(rec[:, 4], g["E"]) < 1e-10
+    assert rel(rec[:, 5], g["Z"]) < 1e-10
+    assert rel(rec[:, 6], g["P"]) < 1e-10
+
+
+G4C = [(128, 1000, 40), (256, 1000, 25), (128, 1000, 400), (256, 1000, 200)]
+
+
+@pytest.mark.parametrize("N,Re,K", G4C)
+def test_trajectory_at_headline_sizes_vs_reference(golden_dir, N, Re, K):
+    """BASELINE configs 3-5 geometry against the REFERENCE's own runs (sg.py:410-449, base.py:250-276) on the launch
+    path: every record, the end state on six rows / columns and the every-8th-node lattice, its norm and maximum."""
+    g = np.load(golden_dir / f"g4c_traj_N{N}_Re{Re}_K{K}.npz")
+    s = make(N, Re, persistent=0)
+    rec = s.run_iterations(K)
+    assert rec.shape == (K, 8)
+    check_g4c(g, s, rec, N)
+
+
 def test_variants_vs_reference(golden_dir):
     g = np.load(golden_dir / "g4b_variants.npz")
     meta = json.loads((golden_dir / "g4b_variants.json").read_text())

@@ -108,6 +108,38 @@ def test_trajectory(golden_dir, N, Re, K):
         assert abs(vm[str(key)] - ref) <= 1e-10 * max(abs(ref), 1.0), key
 
 
+def compact_diffs(a, g, name):
+    """Largest deviations of a 2-D array from the compact form a G4c fixture holds (make_golden._compact_state)."""
+    rows, cols = g[f"{name}_rows_idx"], g[f"{name}_cols_idx"]
+    d = max(np.max(np.abs(a[rows, :] - g[f"{name}_rows"])), np.max(np.abs(a[:, cols] - g[f"{name}_cols"])),
+            np.max(np.abs(a[::8, ::8] - g[f"{name}_lattice"])))
+    dn = abs(np.linalg.norm(a) - float(g[f"{name}_norm2"])) / max(float(g[f"{name}_norm2"]), 1e-300)
+    dm = abs(np.max(np.abs(a)) - float(g[f"{name}_max"]))
+    return d, dn, dm
+
+
+G4C = [(128, 1000, 40), (256, 1000, 25), (128, 1000, 400), (256, 1000, 200)]
+
+
+@pytest.mark.parametrize("N,Re,K", G4C)
+def test_trajectory_at_headline_sizes(golden_dir, N, Re, K):
+    """The reference itself at N=128 / N=256, Re=1000 (BASELINE configs 3-5; sg.py:410-449, base.py:250-276): every
+    record in full, the end state on six rows, six columns and the every-8th-node lattice, its norm and maximum."""
+    g = np.load(golden_dir / f"g4c_traj_N{N}_Re{Re}_K{K}.npz")
+    s = orc.OracleSG(N, float(Re))
+    h = _run(s, K)
+    for name, a in (("u", s.u), ("v", s.v), ("p", s.p)):
+        d, dn, dm = compact_diffs(a, g, name)
+        assert d < 1e-12 and dn < 1e-12 and dm < 1e-12, (name, d, dn, dm)
+    d, dn, dm = compact_diffs(s.vorticity(), g, "omega")
+    assert d < 1e-11 * float(g["omega_max"]) and dn < 1e-11, (d, dn, dm)
+    assert rel(h["dt"], g["dt"]) < 1e-13
+    assert np.max(np.abs(h["rel"] - g["rel"]) / (np.abs(g["rel"]) + 1e-9)) < 1e-9
+    assert rel(h["res"], g["res"]) < 1e-11
+    for k in ("E", "Z", "P"):
+        assert rel(h[k], g[k]) < 1e-11, k
+
+
 @pytest.mark.parametrize("N", [8, 16, 33])
 def test_legendre_operators(golden_dir, N):
     """basis_type='legendre' (sg.py:56-59): LGL nodes, D = Vx V^-1, LGL weights."""
