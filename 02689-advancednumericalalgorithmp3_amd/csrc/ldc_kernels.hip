@@ -1423,6 +1423,12 @@ typedef const __attribute__((address_space(4))) char* kernarg_ptr;
 #include "ldc_cu_kernel.inc"
 
 // ---------------------------------------------------------------------------------------
+// chip-wide trial kernel: a trial's T x T work-groups one per CU on all XCDs, operator panels resident in LDS,
+// write-through tiles + per-work-group flags handed to the row / column mates
+// ---------------------------------------------------------------------------------------
+#include "ldc_wide_kernel.inc"
+
+// ---------------------------------------------------------------------------------------
 // palinstrophy kernel:  P = 1/2 sum W ((Dx w)^2 + (w Dy^T)^2)
 // ---------------------------------------------------------------------------------------
 struct PalinArgs {
@@ -1710,6 +1716,7 @@ struct ldc_batch {
   XArgs* d_xargs[2];         // [with_diagnostics] argument blocks of the small-N trial kernel
   unsigned* d_xsync;         // XG_LEN launch words, then XS_LEN counter words per trial (zeroed before every launch)
   CArgs* d_cargs[2];         // [with_diagnostics] argument blocks of the trial-per-CU kernel
+  WArgs* d_wargs[2];         // [with_diagnostics] argument blocks of the chip-wide kernel
   int post_grid[2], postT_grid, post_close_grid, postP_grid;
   int iters_per_graph;
   hipGraphExec_t graph[2];
@@ -1983,11 +1990,13 @@ bool local_available(const ldc_solver* s) {
 }
 bool xcd_available(const ldc_solver* s);
 bool cu_available(const ldc_solver* s);
+bool wide_available(const ldc_solver* s);
 int xcd_tiles(const ldc_solver* s);
 // 0: launch per stage   1: persistent trial kernel   2: persistent, one-XCD placement   3: small-N trial kernel
-// 4: trial-per-CU kernel
+// 4: trial-per-CU kernel   5: chip-wide trial kernel
 int persistent_mode(const ldc_solver* s) {
   if (s->persist_mode == 0) return 0;
+  if (s->persist_mode == 5) return wide_available(s) ? 5 : 0;
   if (s->persist_mode == 4) return cu_available(s) ? 4 : 0;
   if (s->persist_mode == 3) return xcd_available(s) ? 3 : 0;
   if (s->persist_mode == -1 && xcd_available(s) && xcd_tiles(s) * xcd_tiles(s) <= LDC_XCD_AUTO_TILES) return 3;
@@ -2093,6 +2102,75 @@ int launch_xcd(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
                 LDC_SYNC_XRING + 2 * kXT * kXT * 64 <= LDC_SYNC_LEN, "sync array layout");
   HIP_TRY(hipMemsetAsync(s->p.sync + LDC_SYNC_XLAUNCH, 0, sizeof(uint32_t) * (LDC_SYNC_XFLAGS + XS_LEN - LDC_SYNC_XLAUNCH), st));
   return xcd_launch_any(xl, s->p.stage_pressure != 0, with_diag != 0, T, s->n_xcds, st);
+}
+
+// ---- chip-wide trial kernel (mode 5) ---------------------------------------------------------------------------
+int wide_tiles(const ldc_solver* s) { return (s->p.M + 15) / 16; }
+// one work-group per CU, all of them resident at once; the packed arrays hold T x T blocks; a partial-sum row per tile; the
+// flags and the ring scratch of the trial in its sync array
+bool wide_available(const ldc_solver* s) {
+  const int T = wide_tiles(s);
+  return s->p.sync != nullptr && s->p.Mx == s->p.My && T >= kWTmin && T <= kWT && T * T <= s->n_cus && s->p.LD / 16 >= T &&
+         s->p.partials_stride >= (int64_t)T * T * LDC_NPART && wlds_bytes(T) + 256 <= kLdsLimit;
+}
+bool use_wide(const ldc_solver* s) { return persistent_mode(s) == 5; }
+int enable_wide_lds() {
+  const void* k[3] = {reinterpret_cast<const void*>(wide_kernel<false, false>), reinterpret_cast<const void*>(wide_kernel<false, true>),
+                      reinterpret_cast<const void*>(wide_kernel<true, false>)};
+  for (const void* f : k) {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds_bytes(kWT));
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+
+WArgs make_wargs(const ldc_solver* s, int with_diag) {
+  const ldc_problem& p = s->p;
+  WArgs a;
+  memset(&a, 0, sizeof(a));
+  a.M = p.M; a.LD = p.LD; a.NB = p.LD / 16; a.T = wide_tiles(s);
+  a.tail = 0;
+  a.with_diag = with_diag;
+  a.nu = p.nu; a.beta2 = p.beta2;
+  a.DxK = p.DxK; a.D2xK = p.D2xK; a.DyK = p.DyK; a.D2yK = p.D2yK; a.GxFK = p.GxFK; a.GyFK = p.GyFK;
+  a.ulid = p.ulid; a.wx = p.wx; a.wy = p.wy;
+  a.U = p.U; a.UT = p.UT; a.V = p.V; a.VT = p.VT; a.P = p.P;
+  a.UK[0] = p.UK; a.UK[1] = p.UAK; a.UK[2] = p.UBK;
+  a.UTK[0] = p.UTK; a.UTK[1] = p.UATK; a.UTK[2] = p.UBTK;
+  a.VK[0] = p.VK; a.VK[1] = p.VAK; a.VK[2] = p.VBK;
+  a.VTK[0] = p.VTK; a.VTK[1] = p.VATK; a.VTK[2] = p.VBTK;
+  a.PK[0] = p.PK; a.PK[1] = p.PAK; a.PK[2] = p.PBK;
+  a.PTK[0] = p.T1TK; a.PTK[1] = p.T2TK; a.PTK[2] = p.WTK;     // borrowed (SG uses [0] only, the smoother carries no omega)
+  a.WK = p.WK; a.WTK = p.WTK;
+  a.IxF = p.IxF; a.IyF = p.IyF;
+  a.ring = reinterpret_cast<double*>(p.sync + LDC_SYNC_WRING);
+  a.part4 = p.partials; a.partZ0 = p.partials + p.partials_stride; a.partP0 = p.partials + 3 * p.partials_stride;
+  a.stride = p.partials_stride;
+  a.fin = make_final_args(s, with_diag, 1);
+  a.flags = p.sync + LDC_SYNC_WFLAGS;
+  a.giveup = p.sync + LDC_SYNC_GIVEUP;
+  a.stamps = s->stamps;
+  return a;
+}
+static_assert(LDC_SYNC_WFLAGS + 32 * kWT * kWT <= LDC_SYNC_WRING && LDC_SYNC_WRING + 2 * 2 * 64 * kWT * kWT <= LDC_SYNC_LEN,
+              "sync array layout (chip-wide kernel)");
+
+int wide_launch_any(const WLaunch& wl, int T, bool sp, bool diag, hipStream_t st) {
+  const dim3 grid(wl.B * T * T), block(kStageThreads);
+  const size_t bytes = wlds_bytes(T);
+  if (sp) hipLaunchKernelGGL((wide_kernel<true, false>), grid, block, bytes, st, wl);
+  else if (diag) hipLaunchKernelGGL((wide_kernel<false, true>), grid, block, bytes, st, wl);
+  else hipLaunchKernelGGL((wide_kernel<false, false>), grid, block, bytes, st, wl);
+  return (int)hipGetLastError();
+}
+int launch_wide(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
+  const int T = wide_tiles(s);
+  WLaunch wl;
+  memset(&wl, 0, sizeof(wl));
+  wl.B = 1; wl.n_iters = n_iters; wl.trials = nullptr;
+  wl.one = make_wargs(s, with_diag);
+  HIP_TRY(hipMemsetAsync(s->p.sync + LDC_SYNC_WFLAGS, 0, sizeof(uint32_t) * 32 * T * T, st));
+  return wide_launch_any(wl, T, s->p.stage_pressure != 0, with_diag != 0, st);
 }
 
 // ---- trial-per-CU kernel (mode 4) ------------------------------------------------------------------------------
@@ -2275,7 +2353,7 @@ int ensure_kernel_attributes() {
   if (g_attrs_done[dev]) return 0;
   int e;
   if ((e = enable_stage_lds_all<false>()) != 0 || (e = enable_stage_lds_all<true>()) != 0 || (e = enable_xcd_lds()) != 0 ||
-      (e = enable_cu_lds()) != 0)
+      (e = enable_cu_lds()) != 0 || (e = enable_wide_lds()) != 0)
     return e;
 #ifdef LDC_TIMING
   if ((e = enable_trial_lds()) != 0) return e;
@@ -2508,12 +2586,13 @@ int ldc_solver_set_graph_iters(ldc_solver* s, int n) {
 
 int ldc_solver_set_persistent(ldc_solver* s, int mode) {
   if (!s) return LDC_E_STATE;
-  if (mode < -1 || mode > 4) return LDC_E_ARG;
+  if (mode < -1 || mode > 5) return LDC_E_ARG;
   if ((mode == 1 || mode == 2) && !persistent_available(s)) return LDC_E_ARG;     // (always, in the product build)
   s->persist_mode = mode;
   if (mode == 2 && !local_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }
   if (mode == 3 && !xcd_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }
   if (mode == 4 && !cu_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }
+  if (mode == 5 && !wide_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }
   return 0;
 }
 
@@ -2629,6 +2708,13 @@ int ldc_solver_enqueue(ldc_solver* s, int n_iters, int with_diag, void* stream) 
     // the small-N trial kernel, then the transforms of the final pressure in the launch path's form (row M-1 of the
     // row-major T1T / T2T in the tail layout): whatever runs next finds the state it expects
     int e = launch_xcd(s, n_iters, with_diag, st);
+    if (e) return e;
+    if ((e = launch_post(s, s->p.P, 0, 0, 0, st)) != 0) return e;
+    return with_diag ? launch_closing_diagnostics(s, st) : 0;
+  }
+  if (n_iters > 1 && use_wide(s)) {
+    // the chip-wide trial kernel, then the transforms of the final pressure in the launch path's form
+    int e = launch_wide(s, n_iters, with_diag, st);
     if (e) return e;
     if ((e = launch_post(s, s->p.P, 0, 0, 0, st)) != 0) return e;
     return with_diag ? launch_closing_diagnostics(s, st) : 0;

@@ -16,7 +16,7 @@ LIB_PATH = Path(os.environ.get("LDC_HIP_LIB", _PKG / "lib" / "libldc_hip.so"))
 TIMING_LIB_PATH = _PKG / "lib" / "libldc_hip_timing.so"
 
 REC_LEN, CTRL_LEN, SCAL_LEN, NPART = 8, 8, 8, 12
-SYNC_LEN, SYNC_GIVEUP = 16384, 96
+SYNC_LEN, SYNC_GIVEUP = 98304, 96
 ABI_VERSION = 6
 PERSIST_AUTO_TILES = 0      # LDC_PERSIST_AUTO_TILES of include/ldc_hip.h (auto mode picks the persistent kernel up to here)
 PERSIST_XCD_TILES = 25      # LDC_PERSIST_XCD_TILES: mode 2 (all work-groups of a trial on one XCD) is available up to here

@@ -343,7 +343,7 @@ class SGSolver(LidDrivenCavitySolver):
             # worker threads of a sweep, where torch.cuda.get_device_properties raced inside torch's device bookkeeping
             # ("Invalid device id" once, a process abort another time: round 3, test_gpu_config5_shape_batched_fsg_vs_oracle).
             rc = L.lib().ldc_solver_set_persistent(h, mode)
-            if rc == -1 and mode in (1, 2, 3, 4):
+            if rc == -1 and mode in (1, 2, 3, 4, 5):
                 rc = L.lib().ldc_solver_set_persistent(h, 0)
             L.check(rc, "ldc_solver_set_persistent")
         except Exception:

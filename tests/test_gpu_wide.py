@@ -1,0 +1,125 @@
+"""The chip-wide trial kernel (persistent=5; csrc/ldc_wide_kernel.inc): a trial's ceil(M/16)^2 work-groups one per CU on
+all XCDs, operator panels resident in LDS, write-through tiles + per-work-group flags handed to the row / column mates.
+
+Judged like the small-N kernel: against the REFERENCE (g4c fixtures at N=128: state <= 1e-12, scalars <= 1e-10) and
+against the oracle -- not against the launch path (single accumulation chains: agreement to rounding only).
+"""
+import numpy as np
+import pytest
+
+from oracle import ldc_oracle as orc
+from test_gpu_parity import check_g4c
+from test_gpu_xcd import oracle_rows, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def make(N, Re, **kw):
+    from solvers.spectral.sg import SGSolver
+    args = dict(name="spectral", Re=float(Re), lid_velocity=1.0, Lx=1.0, Ly=1.0, nx=N, ny=N,
+                tolerance=1e-6, max_iterations=10_000_000, basis_type="chebyshev", CFL=1.5,
+                beta_squared=5.0, corner_treatment="smoothing", corner_smoothing=0.15,
+                multigrid="none", check_every=512, graph_iters=16, persistent=5)
+    args.update(kw)
+    return SGSolver(**args)
+
+
+def mode_of(s):
+    from solvers.spectral import ldc_lib as L
+    s._ensure_handle(0.0)
+    return L.lib().ldc_solver_mode(s._handle)
+
+
+@pytest.mark.parametrize("N,Re,K", [(128, 1000, 40), (128, 1000, 400)])
+def test_wide_trajectory_vs_reference(golden_dir, N, Re, K):
+    """The reference's own runs at N=128, Re=1000 (g4c), diagnostics on: 81 work-groups on all XCDs."""
+    g = np.load(golden_dir / f"g4c_traj_N{N}_Re{Re}_K{K}.npz")
+    s = make(N, Re)
+    assert mode_of(s) == 5
+    rec = s.run_iterations(K)
+    assert rec.shape == (K, 8)
+    check_g4c(g, s, rec, N)
+    s.close()
+
+
+@pytest.mark.parametrize("N,Re", [(81, 100), (90, 400), (96, 1000), (100, 400), (111, 100), (112, 400), (128, 400), (140, 1000),
+                                  (160, 100), (176, 400), (200, 1000), (208, 400), (230, 100), (240, 1000), (255, 1000)])
+def test_wide_records_vs_oracle_all_tilings(N, Re):
+    """Every history column against the oracle for T = 6 ... 16 tiles per axis (36 ... 256 work-groups), sizes that are and
+    are not multiples of 16 (the host's tail and non-tail layouts: the kernel re-tiles both as ceil(M/16)), every
+    remainder of T modulo the depth of the fragment ring."""
+    K = 24
+    o = orc.OracleSG(N, Re)
+    want = oracle_rows(o, K)
+    s = make(N, Re)
+    assert mode_of(s) == 5
+    rec = s.run_iterations(K)
+    M = N + 1
+    assert rec.shape == (K, 8)
+    assert np.max(np.abs(s.arrays.u.reshape(M, M) - o.u)) < 1e-12
+    assert np.max(np.abs(s.arrays.v.reshape(M, M) - o.v)) < 1e-12
+    assert np.max(np.abs(s.arrays.p.reshape(M - 2, M - 2) - o.p)) < 1e-12
+    assert rel(rec[:, 7], want[:, 7]) < 1e-12
+    assert np.max(np.abs(rec[:, 0] - want[:, 0]) / (np.abs(want[:, 0]) + 1e-9)) < 1e-8
+    for c in range(1, 7):
+        assert rel(rec[:, c], want[:, c]) < (1e-10 if c < 5 else 1e-9), c
+    s.close()
+
+
+def test_wide_step_only_loop_matches_full_loop():
+    a, b = make(128, 1000.0), make(128, 1000.0)
+    ra = a.run_iterations(60, diagnostics=True)
+    rb = b.run_iterations(60, diagnostics=False)
+    assert np.array_equal(a.arrays.u, b.arrays.u) and np.array_equal(a.arrays.p, b.arrays.p)
+    assert np.array_equal(ra[:, :5], rb[:, :5]) and not rb[:, 5:7].any()
+    a.close(); b.close()
+
+
+def test_wide_sizes_it_does_not_cover_fall_back():
+    for N in (64, 256):                      # one XCD holds N=64 (mode 3 is the faster mapping); N=256 needs 17 x 17 tiles
+        s = make(N, 100.0)
+        assert mode_of(s) == 0
+        s.close()
+
+
+@pytest.mark.parametrize("N,K", [(96, 120), (128, 120)])
+def test_wide_smoother_mode_vs_oracle(N, K):
+    """stage_pressure=1 (FSG levels): every stage differentiates its own stage pressure; the ring in stage 4."""
+    from test_fsg import oracle_records
+    Re = 1000.0
+    s = make(N, Re, check_every=256)
+    s._stage_pressure, s._warmup, s._nan_exit = 1, 0, True
+    assert mode_of(s) == 5
+    rec = s.run_iterations(K, diagnostics=False)
+    o = orc.OracleSG(N, Re, stage_pressure=True)
+    ref = oracle_records(o, K)
+    assert rec.shape[0] == K and np.all(np.isfinite(rec[:, 0]))
+    assert np.max(np.abs(s.arrays.u.reshape(N + 1, N + 1) - o.u)) < 1e-11
+    assert np.max(np.abs(s.arrays.v.reshape(N + 1, N + 1) - o.v)) < 1e-11
+    assert np.max(np.abs(s.arrays.p.reshape(N - 1, N - 1) - o.p)) < 1e-11
+    assert rel(rec[:, 7], ref[:, 7]) < 1e-12
+    for col in range(5):
+        assert np.max(np.abs(rec[:, col] - ref[:, col]) / np.abs(ref[:, col])) < 1e-10, col
+    s.close()
+
+
+def test_wide_and_launch_path_hand_the_state_to_each_other():
+    N, Re = 128, 400.0
+    s = make(N, Re)
+    rows = [s.run_iterations(60)]                      # 1 iteration launch path (edge fix) + 59 chip-wide kernel
+    s.params.persistent = 0
+    rows.append(s.run_iterations(21))
+    s.params.persistent = 5
+    rows.append(s.run_iterations(40))
+    s.params.persistent = 0
+    rows.append(s.run_iterations(1))
+    rec = np.concatenate(rows, axis=0)
+    o = orc.OracleSG(N, Re)
+    want = oracle_rows(o, 122)
+    assert rec.shape == (122, 8)
+    assert np.max(np.abs(s.arrays.u.reshape(N + 1, N + 1) - o.u)) < 1e-12
+    assert np.max(np.abs(s.arrays.p.reshape(N - 1, N - 1) - o.p)) < 1e-12
+    assert rel(rec[:, 7], want[:, 7]) < 1e-12
+    for c in range(1, 7):
+        assert rel(rec[:, c], want[:, c]) < (1e-10 if c < 5 else 1e-9), c
+    s.close()
