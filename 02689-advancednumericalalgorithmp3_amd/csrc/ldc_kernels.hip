@@ -2111,7 +2111,7 @@ int wide_tiles(const ldc_solver* s) { return (s->p.M + 15) / 16; }
 bool wide_available(const ldc_solver* s) {
   const int T = wide_tiles(s);
   return s->p.sync != nullptr && s->p.Mx == s->p.My && T >= kWTmin && T <= kWT && T * T <= s->n_cus && s->p.LD / 16 >= T &&
-         s->p.partials_stride >= (int64_t)T * T * LDC_NPART && wlds_bytes(T) + 256 <= kLdsLimit;
+         s->p.partials_stride >= (int64_t)PS_N * ((T * T + 3) & ~3) && s->p.partials_stride % 4 == 0 && wlds_bytes(T) + 256 <= kLdsLimit;
 }
 bool use_wide(const ldc_solver* s) { return persistent_mode(s) == 5; }
 int enable_wide_lds() {
@@ -2144,6 +2144,7 @@ WArgs make_wargs(const ldc_solver* s, int with_diag) {
   a.WK = p.WK; a.WTK = p.WTK;
   a.IxF = p.IxF; a.IyF = p.IyF;
   a.ring = reinterpret_cast<double*>(p.sync + LDC_SYNC_WRING);
+  a.rvec = a.ring + 64 * kWT * kWT;
   a.part4 = p.partials; a.partZ0 = p.partials + p.partials_stride; a.partP0 = p.partials + 3 * p.partials_stride;
   a.stride = p.partials_stride;
   a.fin = make_final_args(s, with_diag, 1);
@@ -2152,7 +2153,7 @@ WArgs make_wargs(const ldc_solver* s, int with_diag) {
   a.stamps = s->stamps;
   return a;
 }
-static_assert(LDC_SYNC_WFLAGS + 32 * kWT * kWT <= LDC_SYNC_WRING && LDC_SYNC_WRING + 2 * 2 * 64 * kWT * kWT <= LDC_SYNC_LEN,
+static_assert(LDC_SYNC_WFLAGS + 32 * kWT * kWT <= LDC_SYNC_WRING && LDC_SYNC_WRING + 2 * (64 * kWT * kWT + 4 * 16 * kWT) <= LDC_SYNC_LEN,
               "sync array layout (chip-wide kernel)");
 
 int wide_launch_any(const WLaunch& wl, int T, bool sp, bool diag, hipStream_t st) {

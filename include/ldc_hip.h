@@ -99,7 +99,7 @@ enum {
   LDC_SYNC_XFLAGS = 2048, /* its hand-over flags: 32 work-groups, each flag on a 128-byte line of its own */
   LDC_SYNC_XRING  = 8192, /* its scratch for the boundary ring of grad p: 25 tiles x 64 doubles */
   LDC_SYNC_WFLAGS = 16384, /* chip-wide trial kernel (mode 5): hand-over flags, 256 work-groups, each on a 128-byte line of its own */
-  LDC_SYNC_WRING  = 24576, /* its scratch for the boundary ring of grad p: 2 parities x 256 tiles x 64 doubles */
+  LDC_SYNC_WRING  = 24576, /* its scratch for the boundary ring of grad p: 256 tiles x 64 doubles, then the four ring vectors */
   LDC_SYNC_LEN    = 98304
 };
 
