@@ -2105,7 +2105,16 @@ int launch_xcd(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
 }
 
 // ---- chip-wide trial kernel (mode 5) ---------------------------------------------------------------------------
-int wide_tiles(const ldc_solver* s) { return (s->p.M + 15) / 16; }
+// Tail layout (index M-1 outside the tiles: T x T instead of (T+1) x (T+1) work-groups) whenever M = 16 T + 1 and the loop is
+// SG's (the smoother's stages carry their own pressure: its line nodes are not built); LDC_WIDE_LAYOUT=tiles keeps index M-1
+// inside the tiles where that fits (tests run both forms of one size).
+bool wide_tail(const ldc_solver* s) {
+  if ((s->p.M - 1) % 16 != 0 || s->p.stage_pressure != 0) return false;
+  const char* e = getenv("LDC_WIDE_LAYOUT");
+  if (e != nullptr && strcmp(e, "tiles") == 0 && (s->p.M + 15) / 16 <= kWT) return false;
+  return true;
+}
+int wide_tiles(const ldc_solver* s) { return wide_tail(s) ? (s->p.M - 1) / 16 : (s->p.M + 15) / 16; }
 // one work-group per CU, all of them resident at once; the packed arrays hold T x T blocks; a partial-sum row per tile; the
 // flags and the ring scratch of the trial in its sync array
 bool wide_available(const ldc_solver* s) {
@@ -2115,8 +2124,9 @@ bool wide_available(const ldc_solver* s) {
 }
 bool use_wide(const ldc_solver* s) { return persistent_mode(s) == 5; }
 int enable_wide_lds() {
-  const void* k[3] = {reinterpret_cast<const void*>(wide_kernel<false, false>), reinterpret_cast<const void*>(wide_kernel<false, true>),
-                      reinterpret_cast<const void*>(wide_kernel<true, false>)};
+  const void* k[5] = {reinterpret_cast<const void*>(wide_kernel<false, false, false>), reinterpret_cast<const void*>(wide_kernel<false, true, false>),
+                      reinterpret_cast<const void*>(wide_kernel<true, false, false>),
+                      reinterpret_cast<const void*>(wide_kernel<false, false, true>), reinterpret_cast<const void*>(wide_kernel<false, true, true>)};
   for (const void* f : k) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds_bytes(kWT));
     if (e != hipSuccess) return (int)e;
@@ -2129,7 +2139,7 @@ WArgs make_wargs(const ldc_solver* s, int with_diag) {
   WArgs a;
   memset(&a, 0, sizeof(a));
   a.M = p.M; a.LD = p.LD; a.NB = p.LD / 16; a.T = wide_tiles(s);
-  a.tail = 0;
+  a.tail = wide_tail(s) ? 1 : 0;
   a.with_diag = with_diag;
   a.nu = p.nu; a.beta2 = p.beta2;
   a.DxK = p.DxK; a.D2xK = p.D2xK; a.DyK = p.DyK; a.D2yK = p.D2yK; a.GxFK = p.GxFK; a.GyFK = p.GyFK;
@@ -2143,8 +2153,12 @@ WArgs make_wargs(const ldc_solver* s, int with_diag) {
   a.PTK[0] = p.T1TK; a.PTK[1] = p.T2TK; a.PTK[2] = p.WTK;     // borrowed (SG uses [0] only, the smoother carries no omega)
   a.WK = p.WK; a.WTK = p.WTK;
   a.IxF = p.IxF; a.IyF = p.IyF;
+  a.Dx = p.Dx; a.D2x = p.D2x; a.Dy = p.Dy; a.D2y = p.D2y; a.GxF = p.GxF; a.GyF = p.GyF;
+  a.DxL = p.DxL; a.D2xL = p.D2xL; a.DyL = p.DyL; a.D2yL = p.D2yL;
   a.ring = reinterpret_cast<double*>(p.sync + LDC_SYNC_WRING);
   a.rvec = a.ring + 64 * kWT * kWT;
+  a.wedge = a.rvec + 4 * 16 * kWT;
+  a.jobs = a.wedge + 2 * 16 * kWT;
   a.part4 = p.partials; a.partZ0 = p.partials + p.partials_stride; a.partP0 = p.partials + 3 * p.partials_stride;
   a.stride = p.partials_stride;
   a.fin = make_final_args(s, with_diag, 1);
@@ -2153,15 +2167,17 @@ WArgs make_wargs(const ldc_solver* s, int with_diag) {
   a.stamps = s->stamps;
   return a;
 }
-static_assert(LDC_SYNC_WFLAGS + 32 * kWT * kWT <= LDC_SYNC_WRING && LDC_SYNC_WRING + 2 * (64 * kWT * kWT + 4 * 16 * kWT) <= LDC_SYNC_LEN,
+static_assert(LDC_SYNC_WFLAGS + 32 * kWT * kWT <= LDC_SYNC_WRING && LDC_SYNC_WRING + 2 * (64 * kWT * kWT + 6 * 16 * kWT + (2 * kWT + 1) * kWJobDoubles) <= LDC_SYNC_LEN,
               "sync array layout (chip-wide kernel)");
 
-int wide_launch_any(const WLaunch& wl, int T, bool sp, bool diag, hipStream_t st) {
+int wide_launch_any(const WLaunch& wl, int T, bool sp, bool diag, bool tail, hipStream_t st) {
   const dim3 grid(wl.B * T * T), block(kStageThreads);
   const size_t bytes = wlds_bytes(T);
-  if (sp) hipLaunchKernelGGL((wide_kernel<true, false>), grid, block, bytes, st, wl);
-  else if (diag) hipLaunchKernelGGL((wide_kernel<false, true>), grid, block, bytes, st, wl);
-  else hipLaunchKernelGGL((wide_kernel<false, false>), grid, block, bytes, st, wl);
+  if (sp) hipLaunchKernelGGL((wide_kernel<true, false, false>), grid, block, bytes, st, wl);
+  else if (tail && diag) hipLaunchKernelGGL((wide_kernel<false, true, true>), grid, block, bytes, st, wl);
+  else if (tail) hipLaunchKernelGGL((wide_kernel<false, false, true>), grid, block, bytes, st, wl);
+  else if (diag) hipLaunchKernelGGL((wide_kernel<false, true, false>), grid, block, bytes, st, wl);
+  else hipLaunchKernelGGL((wide_kernel<false, false, false>), grid, block, bytes, st, wl);
   return (int)hipGetLastError();
 }
 int launch_wide(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
@@ -2171,7 +2187,7 @@ int launch_wide(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
   wl.B = 1; wl.n_iters = n_iters; wl.trials = nullptr;
   wl.one = make_wargs(s, with_diag);
   HIP_TRY(hipMemsetAsync(s->p.sync + LDC_SYNC_WFLAGS, 0, sizeof(uint32_t) * 32 * T * T, st));
-  return wide_launch_any(wl, T, s->p.stage_pressure != 0, with_diag != 0, st);
+  return wide_launch_any(wl, T, s->p.stage_pressure != 0, with_diag != 0, wide_tail(s), st);
 }
 
 // ---- trial-per-CU kernel (mode 4) ------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from solvers.spectral import ldc_lib as L  # noqa: E402
 from solvers.spectral.sg import SGSolver  # noqa: E402
 
-sizes = [int(x) for x in sys.argv[1:]] or [128, 255]
+sizes = [int(x) for x in sys.argv[1:]] or [128, 256]
 K = int(os.environ.get("AB_K", "2048"))
 MODES = [int(x) for x in os.environ.get("AB_MODES", "0,5").split(",")]
 

@@ -25,7 +25,7 @@ if kind == "smoother":
 diag = kind == "diag"
 s.run_iterations(256, diagnostics=diag)
 assert L.lib().ldc_solver_mode(s._handle) == 5
-T = (s.M - 1) // 16 if (s.M - 1) % 16 == 0 and s.M - 1 == 256 else (s.M + 15) // 16
+T = (s.M - 1) // 16 if ((s.M - 1) % 16 == 0 and kind != "smoother" and os.environ.get("LDC_WIDE_LAYOUT") != "tiles") else (s.M + 15) // 16
 nwg, W, P = T * T, 8, 12
 buf = torch.zeros(nwg * W * 4 * P, dtype=torch.float64, device="cuda")
 L.check(L.lib().ldc_debug_stamps(s._handle, buf.data_ptr()), "ldc_debug_stamps")
