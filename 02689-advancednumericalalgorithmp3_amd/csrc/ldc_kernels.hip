@@ -16,13 +16,11 @@
 //   d/dx  (Dx @ U)[i][j]   = sum_k Dx[i][k] * UT[j][k]
 //   d/dy  (U @ Dy^T)[i][j] = sum_k U [i][k] * Dy[j][k]
 //
-// Two forms of the iteration loop share the arithmetic (K split, order of every sum, the epilogue's explicit FMAs):
-//   launch per RK stage  stage_kernel x 4 + post_kernel (finalize block first, pressure transforms), hipGraph replays;
-//                        the product path at every size
-//   persistent           trial_kernel: all iterations of a chunk in ONE launch, work-groups keep their tile's state in
-//                        registers, a counter barrier per stage; bit-identical, opt-in, measured slower;
-//                        with T*T <= 25 optionally all on ONE XCD, elected at run time (state then crosses through
-//                        that XCD's L2: plain stores, L1-bypassing loads)
+// Forms of the iteration loop (include/ldc_hip.h, ldc_solver_set_persistent):
+//   launch per RK stage  stage_kernel x 4 + post_kernel (finalize block first, pressure transforms), hipGraph replays: every size
+//   small-N kernel       ldc_xcd_kernel.inc: all iterations of a chunk in one launch, the trial's tiles on ONE XCD (N <= 79)
+//   trial-per-CU kernel  ldc_cu_kernel.inc: one work-group = one trial, batches of many small trials (M <= 44)
+//   chip-wide kernel     ldc_wide_kernel.inc: one launch, T x T work-groups one per CU on all XCDs (N = 81 ... 256)
 //
 // MFMA lane maps (v_mfma_f64_16x16x4_f64; pinned by tests/test_gpu_parity.py::test_mfma_lane_maps):
 //   A: lane l holds A[row l&15][k l>>4]      B: lane l holds B[k l>>4][col l&15]
@@ -82,7 +80,7 @@ __device__ __forceinline__ T gl(const T* p, size_t i) {
   return ((const LDC_GLOBAL T*)p)[i];
 }
 
-// ---- coherent forms (COH): what the persistent trial kernel uses for every byte another work-group may have
+// ---- coherent forms (COH): what the persistent kernels (small-N, chip-wide) use for every byte another work-group may have
 // written in the same launch.  Producer side: write-through (sc1) stores, every storing wave's s_waitcnt vmcnt(0),
 // the work-group barrier, ONE lane's agent-scope counter add.  Consumer side: ONE lane polls the counter with
 // sc1 loads, the work-group barrier, then EVERY load of handed-off bytes is an sc1 load to registers (or an sc1
@@ -1408,10 +1406,6 @@ __global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, co
 constexpr unsigned long long kSpinLimitTicks = 200000000ull;    // 2 s of the 100 MHz s_memrealtime counter
 typedef const __attribute__((address_space(4))) char* kernarg_ptr;
 
-#ifdef LDC_TIMING
-#include "ldc_trial_kernel.inc"      // round-2 persistent trial kernel: instrumented build only
-#endif
-
 // ---------------------------------------------------------------------------------------
 // small-N trial kernel: a trial's T x T work-groups on ONE XCD, contraction families per wave, resident operators
 // ---------------------------------------------------------------------------------------
@@ -1696,7 +1690,7 @@ struct ldc_solver {
   double* stamps;            // ldc_debug_stamps
   hipGraphExec_t graph[2];   // [with_diagnostics]
   hipStream_t capture_stream;
-  int persist_mode;          // -1 auto, 0 launch per stage, 1 persistent trial kernel
+  int persist_mode;          // -1 auto, 0 launch per stage, 3 small-N kernel, 4 trial-per-CU kernel, 5 chip-wide kernel
   int n_cus;                 // compute units of the handle's device
   int n_xcds;                // its XCDs (gfx950: 32 active CUs each; a CPX partition is one)
 };
@@ -1955,58 +1949,22 @@ int launch_closing_diagnostics(ldc_solver* s, hipStream_t st) {
   return launch_finalize(s, 1, 0, st);
 }
 
-#ifdef LDC_TIMING
-// ---- round-2 persistent trial kernel (instrumented build only) ------------------------------------------------------------------------------
-constexpr size_t kTrialLdsBytes = TileLds::BYTES;
-static_assert(kTrialLdsBytes <= kLdsLimit, "trial kernel LDS");
-static_assert(kTrialLdsBytes >= sizeof(double) * kThreads * (PS_N + 2), "finalize scratch fits");
-
-int enable_trial_lds() {
-  const void* k[3] = {reinterpret_cast<const void*>(trial_kernel<false, false>),
-                      reinterpret_cast<const void*>(trial_kernel<false, true>),
-                      reinterpret_cast<const void*>(trial_kernel<true, false>)};
-  for (const void* f : k) {
-    // (what the launch asks for, not the 160 KiB limit: the kernel also has a few static words of LDS)
-    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrialLdsBytes);
-    if (e != hipSuccess) return (int)e;
-  }
-  return 0;
-}
-
-#endif
-
-// every work-group of a trial must be resident at once (one per CU: the LDS carve allows no second one)
-bool persistent_available(const ldc_solver* s) {
-#ifdef LDC_TIMING
-  return s->p.sync != nullptr && s->nt <= s->n_cus && s->ablate == 0 && s->p.Mx == s->p.My;
-#else
-  (void)s;
-  return false;               // modes 1 and 2 exist in the instrumented build only (ldc_trial_kernel.inc)
-#endif
-}
-// one-XCD placement: every tile's work-group on the same XCD (one per CU)
-bool local_available(const ldc_solver* s) {
-  return persistent_available(s) && s->nt <= LDC_PERSIST_XCD_TILES && s->nt + 4 <= s->n_cus / s->n_xcds;
-}
 bool xcd_available(const ldc_solver* s);
 bool cu_available(const ldc_solver* s);
 bool wide_available(const ldc_solver* s);
 int xcd_tiles(const ldc_solver* s);
-// 0: launch per stage   1: persistent trial kernel   2: persistent, one-XCD placement   3: small-N trial kernel
-// 4: trial-per-CU kernel   5: chip-wide trial kernel
+// 0: launch per stage   3: small-N trial kernel (one XCD)   4: trial-per-CU kernel   5: chip-wide trial kernel
+// (modes 1 / 2, the round-2 persistent trial kernel, are gone: it lost to mode 0 at every size and to modes 3 / 5 where a
+//  persistent kernel pays -- DESIGN.md 3 keeps its measurements)
 int persistent_mode(const ldc_solver* s) {
   if (s->persist_mode == 0) return 0;
   if (s->persist_mode == 5) return wide_available(s) ? 5 : 0;
   if (s->persist_mode == 4) return cu_available(s) ? 4 : 0;
   if (s->persist_mode == 3) return xcd_available(s) ? 3 : 0;
   if (s->persist_mode == -1 && xcd_available(s) && xcd_tiles(s) * xcd_tiles(s) <= LDC_XCD_AUTO_TILES) return 3;
-  if (!persistent_available(s)) return 0;
-  if (s->persist_mode == 2) return local_available(s) ? 2 : 0;
-  if (s->persist_mode == 1) return 1;
-  if (local_available(s) && s->nt <= LDC_PERSIST_AUTO_XCD_TILES) return 2;
-  return s->nt <= LDC_PERSIST_AUTO_TILES ? 1 : 0;
+  if (s->persist_mode == -1 && wide_available(s)) return 5;      // measured faster than the launch path at every size it covers (profiles/r04_wide_ab_*.log)
+  return 0;
 }
-bool use_persistent(const ldc_solver* s) { const int m = persistent_mode(s); return m == 1 || m == 2; }
 
 // ---- small-N trial kernel (mode 3) -----------------------------------------------------------------------------
 static_assert(XLds::BYTES_NST <= kLdsLimit - 1024, "small-N trial kernel LDS (plus its static words)");
@@ -2270,47 +2228,6 @@ int launch_cu(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
   return cu_launch_any(cl, s, with_diag, st);
 }
 
-#ifdef LDC_TIMING
-TrialArgs make_trial_args(const ldc_solver* s, int n_iters, int with_diag) {
-  TrialArgs ta;
-  memset(&ta, 0, sizeof(ta));
-  for (int k = 0; k < 4; ++k) {
-    ta.st[k] = make_stage_args(s, k);
-    ta.st[k].wt = 1;              // every store of state is write-through: it is what publishes it
-#ifdef LDC_TIMING
-    ta.st[k].ablate = 0;
-#endif
-  }
-  int grid = 0;
-  ta.post = make_post_args(s, s->p.P, 0, 1, with_diag, &grid);
-  ta.post.wt = 1;
-  const double* pst[3] = {s->p.PA, s->p.PB, s->p.PA};
-  const double* pstk[3] = {s->p.PAK, s->p.PBK, s->p.PAK};
-  for (int k = 0; k < 3; ++k) { ta.Pst[k] = pst[k]; ta.PstK[k] = pstk[k]; }
-  ta.n_iters = n_iters;
-  ta.local = persistent_mode(s) == 2 ? 1 : 0;
-  ta.nt = s->nt;
-  ta.sync = s->p.sync;
-  ta.stamps = s->stamps;
-  return ta;
-}
-
-int launch_trial(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
-  const TrialArgs ta = make_trial_args(s, n_iters, with_diag);
-  // the barrier counts arrivals from zero in every launch (the give-up word is sticky: ldc_solver_status)
-  HIP_TRY(hipMemsetAsync(s->p.sync, 0, sizeof(uint32_t) * LDC_SYNC_GIVEUP, st));
-  // one-XCD placement: work-groups are dealt round-robin over the XCDs, so 8 per tile (and some to spare) put at
-  // least T*T of them on whichever XCD is elected; the others leave at once
-  const dim3 grid(ta.local ? s->n_xcds * (s->nt + 8) : s->nt), block(kStageThreads);
-  if (s->p.stage_pressure) hipLaunchKernelGGL((trial_kernel<true, false>), grid, block, kTrialLdsBytes, st, ta);
-  else if (with_diag) hipLaunchKernelGGL((trial_kernel<false, true>), grid, block, kTrialLdsBytes, st, ta);
-  else hipLaunchKernelGGL((trial_kernel<false, false>), grid, block, kTrialLdsBytes, st, ta);
-  return (int)hipGetLastError();
-}
-#else
-int launch_trial(ldc_solver*, int, int, hipStream_t) { return LDC_E_STATE; }      // unreachable: persistent_available() is false
-#endif
-
 // Captures record kernel launches on a private non-blocking stream and nothing else, so no call anywhere needs to be
 // prohibited while one runs: relaxed mode.  (In the stricter modes HIP refuses, for instance, a synchronous copy in
 // ANOTHER host thread while this one captures -- sweeps advance two batches from two threads, solve_concurrently.)
@@ -2372,9 +2289,6 @@ int ensure_kernel_attributes() {
   if ((e = enable_stage_lds_all<false>()) != 0 || (e = enable_stage_lds_all<true>()) != 0 || (e = enable_xcd_lds()) != 0 ||
       (e = enable_cu_lds()) != 0 || (e = enable_wide_lds()) != 0)
     return e;
-#ifdef LDC_TIMING
-  if ((e = enable_trial_lds()) != 0) return e;
-#endif
   g_attrs_done[dev] = true;
   return 0;
 }
@@ -2603,10 +2517,8 @@ int ldc_solver_set_graph_iters(ldc_solver* s, int n) {
 
 int ldc_solver_set_persistent(ldc_solver* s, int mode) {
   if (!s) return LDC_E_STATE;
-  if (mode < -1 || mode > 5) return LDC_E_ARG;
-  if ((mode == 1 || mode == 2) && !persistent_available(s)) return LDC_E_ARG;     // (always, in the product build)
+  if (mode < -1 || mode > 5 || mode == 1 || mode == 2) return LDC_E_ARG;          // (1, 2: the round-2 persistent kernel, removed)
   s->persist_mode = mode;
-  if (mode == 2 && !local_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }
   if (mode == 3 && !xcd_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }
   if (mode == 4 && !cu_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }
   if (mode == 5 && !wide_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }
@@ -2621,10 +2533,22 @@ int ldc_solver_mode(ldc_solver* s) {
 int ldc_solver_status(ldc_solver* s) {
   if (!s) return LDC_E_STATE;
   if (s->p.sync == nullptr) return 0;
+  // (no device-wide synchronise: with two host threads at work that would also wait for the other thread's stream, and HIP
+  //  refuses it outright -- and invalidates the capture -- while the other thread captures a graph: DESIGN.md 3.  The caller
+  //  has waited for the stream its launches ran on; the copy goes through the library's private stream.)
   uint32_t flag = 0;
-  HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(copy_now(&flag, s->p.sync + LDC_SYNC_GIVEUP, sizeof(flag), hipMemcpyDeviceToHost));
   return flag ? LDC_E_SYNC : 0;
+}
+
+int ldc_device_info(int* n_cus, int* n_xcds) {
+  if (!n_cus || !n_xcds) return LDC_E_ARG;
+  int dev = 0, cus = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  *n_cus = cus;
+  *n_xcds = cus >= 64 ? cus / 32 : 1;
+  return 0;
 }
 
 // timing experiments: only the instrumented build (-DLDC_TIMING) has the switches; the product library refuses
@@ -2740,11 +2664,6 @@ int ldc_solver_enqueue(ldc_solver* s, int n_iters, int with_diag, void* stream) 
     int e = launch_cu(s, n_iters, with_diag, st);
     if (e) return e;
     if ((e = launch_post(s, s->p.P, 0, 0, 0, st)) != 0) return e;
-    return with_diag ? launch_closing_diagnostics(s, st) : 0;
-  }
-  if (n_iters > 1 && use_persistent(s)) {
-    const int e = launch_trial(s, n_iters, with_diag, st);
-    if (e) return e;
     return with_diag ? launch_closing_diagnostics(s, st) : 0;
   }
   int left = n_iters;

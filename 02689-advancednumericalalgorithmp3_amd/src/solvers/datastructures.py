@@ -67,10 +67,10 @@ class SpectralParameters(Parameters):
     graph_iters: int = 64          # iterations captured per hipGraph (32 -> 64: -0.2 us per N=256 iteration, flat beyond)
     nan_guard: bool = False        # quirk Q6: the reference SG spins on NaN; True = exit early
     diagnostics: bool = True       # E/Z/P every iteration, as base.py:274-276 does
-    persistent: int = -1           # iteration loop: 0 = one launch per RK stage (hipGraph), 1 = ONE persistent launch
-                                   # per chunk (work-groups keep their tile, counter barrier per stage), 2 = the same
-                                   # with all work-groups of the trial on one XCD (T*T <= 25 tiles, N <= 80),
-                                   # -1 = the library's choice (include/ldc_hip.h); same results in every mode
+    persistent: int = -1           # iteration loop: 0 = one launch per RK stage (hipGraph), 3 = the small-N kernel (one
+                                   # launch per chunk, the trial on one XCD, N <= 79), 4 = the trial-per-CU kernel (M <= 44),
+                                   # 5 = the chip-wide kernel (one launch per chunk, N = 81 ... 256), -1 = the library's
+                                   # choice (include/ldc_hip.h): 3 / 5 where they apply; same results to rounding
 
     def to_mlflow(self) -> dict:
         skip = {"device", "check_every", "graph_iters", "nan_guard", "diagnostics", "persistent"}

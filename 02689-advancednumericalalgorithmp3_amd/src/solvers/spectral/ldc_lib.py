@@ -17,10 +17,7 @@ TIMING_LIB_PATH = _PKG / "lib" / "libldc_hip_timing.so"
 
 REC_LEN, CTRL_LEN, SCAL_LEN, NPART = 8, 8, 8, 12
 SYNC_LEN, SYNC_GIVEUP = 98304, 96
-ABI_VERSION = 6
-PERSIST_AUTO_TILES = 0      # LDC_PERSIST_AUTO_TILES of include/ldc_hip.h (auto mode picks the persistent kernel up to here)
-PERSIST_XCD_TILES = 25      # LDC_PERSIST_XCD_TILES: mode 2 (all work-groups of a trial on one XCD) is available up to here
-PERSIST_AUTO_XCD_TILES = 0  # LDC_PERSIST_AUTO_XCD_TILES: auto mode picks mode 2 up to here
+ABI_VERSION = 7
 XCD_TILES = 25              # LDC_XCD_TILES: mode 3 (the small-N trial kernel) runs trials of up to ceil(M/16)^2 = 25 tiles
 XCD_AUTO_TILES = 25         # LDC_XCD_AUTO_TILES: auto mode picks mode 3 up to here
 CU_MAX_M = 44                # LDC_CU_MAX_M: the trial-per-CU kernel (mode 4) holds the stage state of M <= 44 in one CU's LDS
@@ -88,6 +85,7 @@ def lib() -> C.CDLL:
     L.ldc_solver_set_graph_iters.argtypes = [_dp, C.c_int]
     L.ldc_solver_set_persistent.argtypes = [_dp, C.c_int]
     L.ldc_solver_status.argtypes = [_dp]
+    L.ldc_device_info.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.ldc_solver_mode.argtypes = [_dp]
     L.ldc_batch_mode.argtypes = [_dp]
     L.ldc_stage.argtypes = [_dp, C.c_int, _dp]
@@ -126,7 +124,7 @@ def lib() -> C.CDLL:
 EXPORTS = (
     "ldc_version", "ldc_error_string", "ldc_device_check", "ldc_solver_create", "ldc_solver_destroy",
     "ldc_stage", "ldc_pressure_transform", "ldc_diagnostics", "ldc_finalize", "ldc_prime", "ldc_global_quantities",
-    "ldc_solver_enqueue", "ldc_solver_set_graph_iters", "ldc_solver_set_persistent", "ldc_solver_status", "ldc_solver_mode", "ldc_batch_mode",
+    "ldc_solver_enqueue", "ldc_solver_set_graph_iters", "ldc_solver_set_persistent", "ldc_solver_status", "ldc_solver_mode", "ldc_batch_mode", "ldc_device_info",
     "ldc_residual_debug", "ldc_gemm_nt",
     "ldc_batch_workspace_bytes", "ldc_batch_create", "ldc_batch_destroy", "ldc_batch_enqueue",
     "ldc_poisson_fastdiag", "ldc_vortex_extrema", "ldc_vortex_extrema_xy", "ldc_mfma_selftest", "ldc_mfma_peak", "ldc_debug_ablate", "ldc_debug_stamps",
@@ -134,7 +132,7 @@ EXPORTS = (
 )
 
 
-# Launches whose work-groups must all be resident at once (the persistent modes 1-3) must not overlap each other on one
+# Launches whose work-groups must all be resident at once (modes 3 and 5) must not overlap each other on one
 # device: two of them dispatching from two host threads can each hold part of the CUs (or of an elected XCD) and wait for
 # the rest until the bounded spin gives up (LDC_E_SYNC).  Solvers take this lock around the enqueue + wait of such a chunk;
 # launch-path work of other streams still overlaps with it.

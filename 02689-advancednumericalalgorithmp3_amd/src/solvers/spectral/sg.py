@@ -335,15 +335,15 @@ class SGSolver(LidDrivenCavitySolver):
         try:
             L.check(L.lib().ldc_solver_set_graph_iters(h, int(self.params.graph_iters)), "ldc_solver_set_graph_iters")
             mode = int(self.params.persistent)
-            # A persistent mode on a size it cannot run (mode 2 / 3: more tiles than one XCD holds; mode 4: more state than one
-            # CU's LDS holds; mode 1: more tiles than
-            # the device has CUs, e.g. the fine level of a hierarchy) falls back to the launch path -- all the same way:
+            # A persistent mode on a size it cannot run (mode 3: more tiles than one XCD holds; mode 4: more state than one
+            # CU's LDS holds; mode 5: fewer than 6 x 6 or more than 16 x 16 tiles, e.g. the levels of a hierarchy) falls back
+            # to the launch path -- all the same way:
             # a configuration asks for "persistent where it applies", the levels of one FSG solve differ in size.  The
             # library knows the device (CUs, XCDs) and says LDC_E_ARG; nothing is asked of torch here: this runs in the
             # worker threads of a sweep, where torch.cuda.get_device_properties raced inside torch's device bookkeeping
             # ("Invalid device id" once, a process abort another time: round 3, test_gpu_config5_shape_batched_fsg_vs_oracle).
             rc = L.lib().ldc_solver_set_persistent(h, mode)
-            if rc == -1 and mode in (1, 2, 3, 4, 5):
+            if rc == -1 and mode in (3, 4, 5):
                 rc = L.lib().ldc_solver_set_persistent(h, 0)
             L.check(rc, "ldc_solver_set_persistent")
         except Exception:

@@ -16,9 +16,8 @@
  *    hipGraph executables.  It belongs to the HIP device that is current when it is created
  *    (dynamic-LDS attributes of its kernels are set there); using it with another device
  *    current returns LDC_E_STATE.
- *  - one grid per solve: the same number of nodes M on both axes (the reference builds
- *    independent x / y grids, sg.py:103-119, but every configuration it ships sets nx = ny = N;
- *    the plugin class raises NotImplementedError for nx != ny).  Lx != Ly is supported.
+ *  - grids: M nodes per axis; independent x / y grids (reference sg.py:103-119: nx != ny; no shipped
+ *    configuration uses it) through ldc_problem::Mx / My below (launch path only).  Lx != Ly is supported.
  *  - all 2-D arrays are row-major LD x LD doubles, zero padded, element [ix][iy]
  *    (reference sg.py:108, indexing="ij"); LD is a multiple of 16 and >= 16*T + 16.
  *  - "transposed copy" XT means XT[iy][ix] = X[ix][iy]; the kernels keep both so that
@@ -44,12 +43,12 @@
 extern "C" {
 #endif
 
-#define LDC_ABI_VERSION 6
+#define LDC_ABI_VERSION 7
 
 #define LDC_E_ARG      (-1)  /* null pointer / inconsistent geometry */
 #define LDC_E_STATE    (-2)  /* handle not valid for the call */
 #define LDC_E_NODEVICE (-3)  /* no HIP device / wrong architecture */
-#define LDC_E_SYNC     (-4)  /* persistent trial kernel: a grid-barrier wait was given up (ldc_solver_status) */
+#define LDC_E_SYNC     (-4)  /* a persistent kernel (modes 3, 5) gave up a bounded wait for another work-group (ldc_solver_status) */
 
 /* slots of one history record written per iteration (ldc_problem.rec) */
 enum {
@@ -88,12 +87,9 @@ enum {
 
 #define LDC_NPART 12   /* doubles per work-group in `partials` */
 
-/* sync[] (uint32) slots of the persistent trial kernel; each on a 128-byte line of its own */
+/* sync[] (uint32) slots of the persistent kernels */
 enum {
-  LDC_SYNC_ARRIVE = 0,   /* arrival counter of the barrier among the trial's work-groups          */
-  LDC_SYNC_XCC    = 32,  /* one-XCD placement: 1 + HW XCC id the first arriving work-group elected */
-  LDC_SYNC_HEAD   = 64,  /* one-XCD placement: next tile to be claimed by a work-group of that XCD */
-  LDC_SYNC_GIVEUP = 96,  /* set to 1 by a work-group whose bounded wait on the counter ran out    */
+  LDC_SYNC_GIVEUP = 96,  /* set to 1 by a work-group whose bounded wait for another one ran out     */
   LDC_SYNC_XLAUNCH = 128, /* small-N trial kernel (mode 3): the launch words of a single-trial launch (tickets per XCD,
                              the trial each XCD slot took) */
   LDC_SYNC_XFLAGS = 2048, /* its hand-over flags: 32 work-groups, each flag on a 128-byte line of its own */
@@ -203,12 +199,8 @@ int ldc_solver_enqueue(ldc_solver *s, int n_iters, int with_diagnostics, void *s
 /* iterations captured per graph (default 64); must be set before the first enqueue      */
 int ldc_solver_set_graph_iters(ldc_solver *s, int iters_per_graph);
 /* How ldc_solver_enqueue runs the loop.  mode 0: one launch per RK stage (hipGraph replay).                       */
-/* modes 1 and 2: the round-2 persistent trial kernel (csrc/ldc_trial_kernel.inc: T*T work-groups that keep their   */
-/* tile and meet at a counter barrier per stage; 2 = all of them on one XCD).  INSTRUMENTED BUILD ONLY               */
-/* (ldc_timing_build() == 1): it lost to mode 0 at every size and to mode 3 where a persistent kernel pays, so the   */
-/* product library does not carry it and answers LDC_E_ARG; there it needs desc->sync, T*T <= CUs (mode 2:           */
-/* T*T <= LDC_PERSIST_XCD_TILES) and gives records bit-identical to mode 0.                                          */
-/* -1 (default): mode 3 where it applies and ceil(M/16)^2 <= LDC_XCD_AUTO_TILES, else mode 0.                         */
+/* (modes 1 and 2 -- the round-2 persistent trial kernel -- were removed with ABI 7: LDC_E_ARG.)                       */
+/* -1 (default): mode 3 where it applies and ceil(M/16)^2 <= LDC_XCD_AUTO_TILES, else mode 5 where it applies, else mode 0.  */
 /* mode 3: the small-N trial kernel (csrc/ldc_xcd_kernel.inc) -- ALL n_iters iterations in one launch, the trial's     */
 /* ceil(M/16)^2 work-groups on ONE XCD elected at run time, one contraction family per wave over the full contraction   */
 /* index, the operator fragments resident in registers, state exchanged through that XCD's L2, the pressure path and    */
@@ -217,9 +209,6 @@ int ldc_solver_set_graph_iters(ldc_solver *s, int iters_per_graph);
 /* mixed with the launch path; trajectories agree with the launch path to rounding, not bit for bit (one accumulation   */
 /* chain per contraction instead of four K-quarters).  In mode -1 it is chosen when ceil(M/16)^2 <= LDC_XCD_AUTO_TILES.  */
 /* A batch (ldc_batch_enqueue) whose trials all resolve to mode 3 runs every trial on an XCD of its own in one launch.   */
-#define LDC_PERSIST_AUTO_TILES 0
-#define LDC_PERSIST_XCD_TILES 25        /* one work-group per CU, 32 CUs per XCD, room left for the over-subscription to drain */
-#define LDC_PERSIST_AUTO_XCD_TILES 0
 #define LDC_XCD_TILES 25
 #define LDC_XCD_AUTO_TILES 25      /* measured faster than the launch path at every size it applies to (profiles/r03_xcd_ab.log) */
 /* mode 4: the trial-per-CU kernel (csrc/ldc_cu_kernel.inc) -- ONE work-group advances the trial: the stage state and the  */
@@ -230,6 +219,15 @@ int ldc_solver_set_graph_iters(ldc_solver *s, int iters_per_graph);
 /* entry and exit state as mode 3 (row-major phi^n in, row-major and packed forms out); trajectories agree with the other   */
 /* paths to rounding.                                                                                                       */
 #define LDC_CU_MAX_M 44
+/* mode 5: the chip-wide trial kernel (csrc/ldc_wide_kernel.inc) -- ALL n_iters iterations in one launch, the trial's T x T      */
+/* work-groups ONE PER CU ON ALL XCDs (T = ceil(M/16), 6 <= T <= 16; for M = 16 T + 1 and the SG loop the tail layout: index M-1   */
+/* outside the tiles, N = 96, 112 ... 256 on T x T work-groups), the four operator panels of a tile resident in LDS, one           */
+/* contraction family per wave over the full contraction index, state exchanged through the fabric as write-through tiles +       */
+/* one flag per work-group handed to the 2T-1 work-groups of its tile row and column, the fold of the partial sums beside the     */
+/* contractions of stage 1.  Needs desc->sync and T*T <= CUs, all of them free (one work-group per CU must be resident at once:   */
+/* LDC_E_SYNC after a bounded wait otherwise); the smoother at M = 16 T + 1 = 257 has no such form (LDC_E_ARG).  Entry and exit    */
+/* state as mode 3; trajectories agree with the other paths to rounding.  Chosen in mode -1 wherever it applies and mode 3 does   */
+/* not (N = 81 ... 256).                                                                                                          */
 /* (measured, profiles/r03_cu_ab.log: the trial-per-CU kernel scales with the number of trials up to 256, the small-N kernel    */
 /*  saturates where its XCDs are full -- 64 trials at ceil(M/16) <= 2 (5.7 M trial-iterations/s), 8 ... 24 above (1.9 M); the    */
 /*  thresholds are where the two lines cross: profiles/r03_cu_ab_thresholds.log)                                                                                     */
@@ -239,11 +237,15 @@ int ldc_solver_set_graph_iters(ldc_solver *s, int iters_per_graph);
 int ldc_solver_set_persistent(ldc_solver *s, int mode);
 /* the mode ldc_solver_enqueue will really use for more than one iteration (0, 1, 2, 3 or 4): what set_persistent asked   */
 /* for, resolved against what the handle's size and device allow.  A host that drives several streams uses it to keep  */
-/* launches that need co-resident work-groups (modes 1-3) from overlapping each other.                                 */
+/* launches that need co-resident work-groups (modes 3, 5) from overlapping each other.                                */
 int ldc_solver_mode(ldc_solver *s);
-/* 0, or LDC_E_SYNC when a persistent launch of this handle gave up a barrier wait (a work-group was not         */
-/* resident): the state is then undefined.  Reads desc->sync on the host: SYNCHRONISES the device.               */
+/* 0, or LDC_E_SYNC when a persistent launch of this handle gave up a bounded wait (a work-group was not         */
+/* resident): the state is then undefined.  Reads one word of desc->sync on the host, through the library's      */
+/* private stream: the CALLER has waited for the stream its launches ran on (no device-wide synchronise here: a  */
+/* sweep drives the library from several host threads, and HIP refuses that call while another thread captures).  */
 int ldc_solver_status(ldc_solver *s);
+/* compute units and XCDs of the current device as the library counts them (what modes 3 / 5 size their launches by) */
+int ldc_device_info(int *n_cus, int *n_xcds);
 
 /* batched trials (the sweep axis of the reference on ONE GPU): n_trials solver handles of      */
 /* identical geometry (M, LD, mode) advanced by the same launches, blockIdx.y = trial; each     */

@@ -17,7 +17,7 @@ import os
 import sys
 from collections import defaultdict
 
-KEEP = ("stage_kernel", "post_kernel", "palin_kernel", "finalize_kernel", "prime_kernel", "trial_kernel")
+KEEP = ("stage_kernel", "post_kernel", "palin_kernel", "finalize_kernel", "prime_kernel", "wide_kernel", "xcd_kernel", "cu_kernel")
 
 
 def short(name):
