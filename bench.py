@@ -16,11 +16,14 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE J
 * ghia      : the metric's second half (Ghia centreline error of the bench config) from the committed
               converged-solve reports (profiles/r01_ghia_report.json, r02_ghia_tight.json) -- labelled as a
               committed report, not a live measurement (those solves take 1-56 GPU-minutes).
-* roofline  : dominant kernel = the fused RK-stage kernel (plain variant, 2 of the 4
-              stage launches of a step).  `achieved` = necessary flops per launch (SURVEY 8d:
-              8 contractions x 2 M^3 = 16 M^3) over the mean launch time measured with HIP
-              events around back-to-back launches on the launch stream; `peak` = 78.6 TFLOP/s
-              fp64 matrix (AMD datasheet).  `peak_measured` is the SUSTAINED fp64 MFMA rate of a
+* roofline  : dominant kernel of the path the solver really takes.  At N=256 that is the chip-wide trial kernel
+              (csrc/ldc_wide_kernel.inc, mode 5): ONE launch runs every iteration of a chunk, so a launch's
+              algorithmic flops are `iterations_per_launch` x the necessary flops of one full iteration (SURVEY 8d:
+              76 M^3 + 2 M Mi (M + Mi)) and `launch_us` is measured with HIP events around launches of
+              `iterations_per_launch` = 2048 iterations on the launch stream (the three small launches that close a
+              chunk's last record ride along: 0.03 % of it).  `launch_path` holds the same figures for the launch
+              path's dominant kernel (the fused RK-stage kernel, 16 M^3 per launch, back-to-back launches), which
+              was the headline path until round 3.  `peak` = 78.6 TFLOP/s fp64 matrix (AMD datasheet).  `peak_measured` is the SUSTAINED fp64 MFMA rate of a
               micro-benchmark in this run (~48 TFLOP/s: one v_mfma_f64_16x16x4 per ~100 cycles per
               SIMD over 32 000 back-to-back MFMAs per wave) -- a power/clock figure, not the issue
               limit: the 4-us K loop of the stage kernel runs at ~65 TFLOP/s.
@@ -35,6 +38,10 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE J
 * small_n   : BASELINE.json configs[1] (N=64, Re=400) on the same GPU: full iterations per second through the small-N
               trial kernel (what the solver picks by default at N <= 79) and through the launch path (N = 1 only).
 * cu_batch   : 256 trials of N=32 in one batch (N = 1 only): trial-iterations per second through the trial-per-CU kernel.
+* --gpus N  : started plainly (no WORLD_SIZE in the environment) with N > 1, the process starts N ranks of itself through
+              torch.distributed.run BEFORE it touches the GPU, relays rank 0's JSON line and exits with the ranks' code.
+* --headline-only : the headline, its roofline block and nothing else (no farm / small_n / cu_batch / cpu legs): what
+              tools/profile_round.py runs under rocprofv3 so that the kernel statistics carry the N=256 launches alone.
 * farm      : a second, sweep-shaped measurement for the multi-GPU runs -- every rank advances `trials_per_gpu`
               equal-N trials the way main.py advances the trials a rank owns in the Hydra multirun / Optuna search:
               two batches with shared launches, side by side on two HIP streams of different priority;
@@ -142,19 +149,20 @@ def farm_rate(N, B, device, dist, seconds=0.3):
             n += K
         b.iterations_timed = n
 
-    # three windows, the best one counts (a window is 0.3 s of two host threads racing each other: single windows of one
-    # box read 105 ... 131 k trial-iterations/s)
-    best = 0.0
-    for _ in range(3):
+    # five windows, the MEDIAN counts and the spread is reported (a window is 0.3 s of two host threads racing each other:
+    # single windows of one box read 105 ... 131 k trial-iterations/s)
+    rates = []
+    for _ in range(5):
         dist.barrier(); torch.cuda.synchronize()
         dt = run_concurrently(halves, advance, device)
         torch.cuda.synchronize()
         done = sum(len(b) * b.iterations_timed for b in halves)
-        if done / dt > best:
-            best, state["n"] = done / dt, min(b.iterations_timed for b in halves)
+        rates.append(done / dt)
+        state["n"] = min(b.iterations_timed for b in halves)
     for b in halves:
         b.close()
-    return best, state["n"]
+    rates.sort()
+    return rates[len(rates) // 2], state["n"], rates[0], rates[-1]
 
 
 def stage_kernel_time(s, bursts=20, pairs_per_burst=100):
@@ -178,6 +186,26 @@ def stage_kernel_time(s, bursts=20, pairs_per_burst=100):
         times.append(e0.elapsed_time(e1) * 1e-3 / (2 * pairs_per_burst))
     times.sort()
     return times[len(times) // 2]
+
+
+def persistent_launch_time(s, K=2048, reps=5):
+    """Median duration of one launch of the persistent kernel that runs the loop (mode 3 / 5): HIP events on the launch
+    stream around an enqueue of K full iterations (one launch of the trial kernel + the three small launches that close
+    the chunk's last record)."""
+    import torch
+    from solvers.spectral import ldc_lib as L
+    lib, h, st = L.lib(), s._handle, L.stream_ptr()
+    t = []
+    for _ in range(reps + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        L.check(lib.ldc_solver_enqueue(h, K, 1, st), "enqueue")
+        e1.record()
+        torch.cuda.synchronize()
+        t.append(e0.elapsed_time(e1) * 1e-3)
+    t = sorted(t[1:])
+    return t[len(t) // 2], K
 
 
 def mfma_peak_measured():
@@ -243,13 +271,29 @@ def cpu_baseline(N, Re, budget_s=14.0):
             rate = 6 / (time.perf_counter() - t0)
         if rate > best_rate:
             best, best_rate = c, rate
+    with threadpool_limits(limits=1, user_api="blas"):
+        one()
+        n1, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 3.0:
+            one()
+            n1 += 1
+        rate1 = n1 / (time.perf_counter() - t0)
     with threadpool_limits(limits=best, user_api="blas"):
         n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < budget_s:
+        while time.perf_counter() - t0 < budget_s - 3.0:
             one()
             n += 1
         dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="steps/s", cores=int(best), kind="port",
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(value=n / dt, unit="steps/s", cores=int(best), kind="port", value_1thread=rate1, cpu_model=model,
+                cpus_available=int(cap),
                 sample=f"{n} full solve() iterations (step + norms + E/Z/P) of the NumPy oracle at "
                        f"N={N}, Re={Re:g} from rest, {dt:.1f} s, OpenBLAS {best} threads "
                        f"(best of {cands}; {cap} CPUs available)")
@@ -264,17 +308,30 @@ def _plain_stage_entry(kernels: dict):
     return None
 
 
-def pmc_traffic(N):
+def _wide_entry(kernels: dict):
+    """The chip-wide kernel's entry of a PMC summary (SG with diagnostics, tail layout: the N=256 headline)."""
+    for name, v in kernels.items():
+        if name.startswith("wide_kernel<false, true, true>"):
+            return v
+    return None
+
+
+def pmc_traffic(N, wide=False):
     """HBM/fabric bytes per launch of the dominant kernel from the committed PMC passes
     (profiles/r*_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of tools/pmc_run.py at
-    N=256, gfx950 correction applied as MI355X_MICROARCH.md prescribes).  None for other sizes."""
+    N=256, gfx950 correction applied as MI355X_MICROARCH.md prescribes).  None for other sizes, and for the chip-wide kernel
+    until a pass of it is committed (the figure is then per launch of `iterations_per_launch` iterations)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if N != 256 or not files:
-        return None, None
-    with open(files[-1]) as f:
-        k = _plain_stage_entry(json.load(f)["kernels"])
-    return (k["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)) if k else (None, None)
+        return None, None, None
+    for f in reversed(files):
+        with open(f) as fh:
+            d = json.load(fh)
+        k = _wide_entry(d["kernels"]) if wide else _plain_stage_entry(d["kernels"])
+        if k and "hbm_bytes_per_launch" in k:
+            return k["hbm_bytes_per_launch"], os.path.relpath(f, ROOT), k.get("iterations_per_launch")
+    return None, None, None
 
 
 def pmc_mfma_util(N, launch_seconds):
@@ -378,17 +435,19 @@ def cu_batch_block(device, N=32, B=256, K=2048):
     b = BatchedSGSolver(trials)
     b.run_iterations(64, diagnostics=False)
     mode = int(L.lib().ldc_batch_mode(b._batch))
-    best = 0.0
-    for _ in range(3):
+    rates = []
+    for _ in range(5):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         b.run_iterations(K, diagnostics=False)
         torch.cuda.synchronize()
-        best = max(best, B * K / (time.perf_counter() - t0))
+        rates.append(B * K / (time.perf_counter() - t0))
     rec = b.solvers[B - 1].d["rec"].cpu().numpy()
     assert bool((rec == rec).all()), "non-finite history record in the batch of small trials"
     b.close()
-    return {"value": best, "unit": "trial-iterations/s", "N": N, "trials": B, "iterations_per_chunk": K, "batch_mode": mode,
+    rates.sort()
+    return {"value": rates[len(rates) // 2], "statistic": "median of 5 chunks", "min": rates[0], "max": rates[-1],
+            "unit": "trial-iterations/s", "N": N, "trials": B, "iterations_per_chunk": K, "batch_mode": mode,
             "workload": f"{B} SG trials of N={N} in one batch on one GPU (step()-only loop), one work-group per trial"}
 
 
@@ -402,20 +461,65 @@ def main():
     ap.add_argument("--Re", type=float, default=WORKLOAD["Re"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-farm", action="store_true", help="skip the batched-trials (sweep-shaped) measurement")
-    ap.add_argument("--persistent", type=int, default=-1, help="-1 auto, 0 launch per stage, 3 small-N trial kernel (N <= 79)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="the headline and its roofline block only (what tools/profile_round.py profiles)")
+    ap.add_argument("--leg", default="", choices=["", "farm", "small_n", "cu_batch"],
+                    help="ONE secondary leg only (no headline): what tools/profile_round.sh profiles leg by leg")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: the launcher, the rendezvous, the barrier, the max-over-ranks and the gather only (CPU test of --gpus N)")
+    ap.add_argument("--persistent", type=int, default=-1,
+                    help="-1 the library's choice (N=256: the chip-wide kernel), 0 launch per stage, 3 / 5 the persistent kernels")
     a = ap.parse_args()
+    if a.headline_only:
+        a.no_cpu = a.no_farm = True
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started plainly: become the launcher.  N fresh ranks of this script through torch.distributed.run, BEFORE anything
+        # here has touched the GPU (a process that has initialised HIP must never be replaced or forked into ranks); rank
+        # 0's JSON line is relayed, the exit code is the ranks'.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+        if lines:
+            print(lines[-1])
+        else:
+            sys.stdout.write(r.stdout)
+        raise SystemExit(r.returncode if r.returncode != 0 or lines else 1)
 
     import torch
     from utilities.sweep.farm import Dist
     dist = Dist()
     rank, world, local = dist.rank, dist.world, dist.local_rank
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: start bench.py plainly (it launches its own ranks) or with {a.gpus} ranks")
+    if a.dry_run:
+        # the multi-rank flow without a device: what tests/test_bench_cpu.py runs through the plain command on CPU
+        dist.init("gloo")
+        dist.barrier()
+        t = dist.max_float(1e-3 * (1 + rank))
+        got = dist.all_gather_object(rank)
+        dist.barrier()
+        dist.close()
+        if rank == 0:
+            print(json.dumps({"metric": "steady-state time-steps/sec at N=256 Re=1000", "dry_run": True, "value": None,
+                              "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ranks_seen": got, "max_over_ranks_s": t}))
+        return
     # (LDC_DIST_BACKEND=gloo + fewer cards than ranks: a rehearsal of the multi-rank flow on a one-GPU box; the ranks
     #  then share the card and the rates mean nothing)
+    shared_card = world > max(1, torch.cuda.device_count())
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dist.local_rank = local
+    if shared_card and a.persistent != 0:
+        # ranks that share a card cannot both have a work-group on every CU: the persistent kernels (whose work-groups wait
+        # for each other) would each hold part of the chip until their bounded waits give up -- launch path for the rehearsal
+        a.persistent = 0
     # The ranks never exchange device data: the barrier and the max-over-ranks of the elapsed time are host objects, and
     # gloo carries those (as main.py's farm does under LDC_DIST_BACKEND=gloo) -- the replicas-only design needs no RCCL.
     dist.init(os.environ.get("LDC_DIST_BACKEND", "gloo"))
@@ -427,12 +531,27 @@ def main():
     barrier()
     g._paths()
 
+    if a.leg:
+        # one secondary leg alone (so that a rocprofv3 pass over this command holds that leg's launches only)
+        if a.leg == "farm":
+            rate, n_it, r_lo, r_hi = farm_rate(128, 8, f"cuda:{local}", dist)
+            leg = {"value": rate, "min": r_lo, "max": r_hi, "unit": "trial-iterations/s", "N": 128, "trials_per_gpu": 8}
+        elif a.leg == "small_n":
+            leg = small_n_block(f"cuda:{local}")
+        else:
+            leg = cu_batch_block(f"cuda:{local}")
+        dist.close()
+        if rank == 0:
+            print(json.dumps({"leg": a.leg, a.leg: leg}))
+        return
+
     gi = int(os.environ.get("LDC_BENCH_GRAPH_ITERS", graph_iters_for(a.steps)))       # (the override is for experiments)
     s = make_solver(a.N, a.Re, f"cuda:{local}", graph_iters=gi, persistent=a.persistent)
     s._begin(0.0)
     from solvers.spectral import ldc_lib as L
     mode = int(L.lib().ldc_solver_mode(s._handle))         # what the library resolved: 0 launch per stage, 3 small-N kernel
-    launch_path = "persistent" if mode != 0 else ("graph" if a.steps % gi == 0 else "graph+eager")
+    launch_path = ({3: "persistent (small-N kernel)", 4: "persistent (trial-per-CU kernel)", 5: "persistent (chip-wide kernel)"}.get(mode, "persistent")
+                   if mode != 0 else ("graph" if a.steps % gi == 0 else "graph+eager"))
     # warm-up (also instantiates both hipGraphs): W untimed steps, at least two full captures
     timed_iterations(s, max(a.warmup, 2 * gi), True, barrier)
     timed_iterations(s, 2 * gi, False, barrier)
@@ -443,16 +562,17 @@ def main():
     assert int(ctrl[0]) == 0, "latch fired during the bench (tolerance is 0: must not happen)"
     rec = s.d["rec"].cpu().numpy()
     assert bool((rec == rec).all()), "non-finite history record: the timed run diverged"
-    if launch_path == "persistent":     # a persistent launch that gave up a barrier wait leaves undefined state, not a rate
+    if mode != 0:     # a persistent launch that gave up a barrier wait leaves undefined state, not a rate
         assert L.lib().ldc_solver_status(s._handle) == 0, "persistent kernel gave up a barrier wait (LDC_E_SYNC)"
 
     farm = None
     if not a.no_farm:
         fN, fB = 128, 8                       # config 5's shape: N = 128, 64 trials over 8 GPUs = 8 per GPU and round
-        rate, n_it = farm_rate(fN, fB, f"cuda:{local}", dist)
+        rate, n_it, r_lo, r_hi = farm_rate(fN, fB, f"cuda:{local}", dist)
         rates = dist.all_gather_object(rate)
         farm = {"value": float(sum(rates)), "unit": "trial-iterations/s", "n_gpus": world, "trials_per_gpu": fB, "N": fN,
                 "per_gpu": [float(r) for r in rates], "iterations_timed_per_trial": n_it,
+                "windows": 5, "statistic": "median of the windows", "rank0_min": float(r_lo), "rank0_max": float(r_hi),
                 "streams": max(1, min(int(os.environ.get("LDC_BATCH_STREAMS", "3")), 2, fB)),
                 "workload": f"{fB} SG trials of N={fN} per GPU as main.py advances the trials a rank owns: two batches with "
                             "shared launches on two HIP streams (step()-only loop)",
@@ -464,17 +584,63 @@ def main():
 
     out = None
     if rank == 0:
-        t_stage = stage_kernel_time(s)
         M = a.N + 1
-        f_launch = 16.0 * M**3          # 8 contractions x 2 M^3 (stage 1 adds 4 M^3 for grad p)
-        achieved = f_launch / t_stage / 1e12
         peak_meas = mfma_peak_measured()
-        traffic, traffic_src = pmc_traffic(a.N)
+        f_iter = flops_per_step(a.N, True)
+        if mode != 0:
+            # the persistent kernel that runs the loop: one launch = every iteration of a chunk
+            t_launch, k_launch = persistent_launch_time(s)
+            f_launch = k_launch * f_iter
+            achieved = f_launch / t_launch / 1e12
+            traffic, traffic_src, traffic_iters = pmc_traffic(a.N, wide=True)
+            if traffic is not None and traffic_iters:
+                traffic = traffic / traffic_iters * k_launch        # the PMC pass's launch holds `traffic_iters` iterations
+            kname = {3: "xcd_kernel (small-N trial kernel: all iterations of a chunk in one launch, one XCD)",
+                     4: "cu_kernel (trial-per-CU kernel)",
+                     5: "wide_kernel<SG, E/Z/P" + (", tail layout" if (a.N % 16 == 0) else "") + "> (chip-wide trial kernel: all "
+                        "iterations of a chunk in one launch, one work-group per CU)"}.get(mode, f"mode {mode}")
+            roof = {"bound": "mfma", "kernel": kname, "mode": mode, "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
+                    "traffic": traffic, "traffic_unit": "bytes/launch (FETCH_SIZE+WRITE_SIZE)", "traffic_source": traffic_src,
+                    "traffic_basis": (f"PMC pass of a launch of {traffic_iters} iterations, scaled to iterations_per_launch"
+                                      if traffic_iters else None),
+                    "flops_per_launch": f_launch, "launch_us": t_launch * 1e6, "iterations_per_launch": k_launch,
+                    "flops_per_iteration": f_iter, "us_per_iteration_in_launch": t_launch * 1e6 / k_launch,
+                    "peak_measured": peak_meas, "frac_of_measured": achieved / peak_meas}
+            # the launch path's dominant kernel beside it (the headline path until round 3): same solver state, mode 0
+            s0 = make_solver(a.N, a.Re, f"cuda:{local}", graph_iters=gi, persistent=0)
+            s0._begin(0.0)
+            timed_iterations(s0, 2 * gi, True, lambda: None)
+            t_stage = stage_kernel_time(s0)
+            w0, _, _ = timed_regions(s0, a.steps, True, dist) if world == 1 else (None, None, None)
+            s0.close()
+            a_stage = 16.0 * M**3 / t_stage / 1e12
+            roof["launch_path"] = {"kernel": "stage_kernel<GP=0,LAST=0,DUMP=0> (fused RK stage, one launch per stage)",
+                                   "flops_per_launch": 16.0 * M**3, "launch_us": t_stage * 1e6, "achieved": a_stage,
+                                   "frac": a_stage / PEAK_FP64_MFMA_TFLOPS,
+                                   "value": (a.steps / w0) if w0 else None, "ms_per_step": (1e3 * w0 / a.steps) if w0 else None}
+        else:
+            t_stage = stage_kernel_time(s)
+            f_launch = 16.0 * M**3          # 8 contractions x 2 M^3 (stage 1 adds 4 M^3 for grad p)
+            achieved = f_launch / t_stage / 1e12
+            traffic, traffic_src, _ = pmc_traffic(a.N)
+            roof = {"bound": "mfma", "kernel": "stage_kernel<GP=0,LAST=0,DUMP=0> (fused RK stage)", "mode": 0, "achieved": achieved,
+                    "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
+                    "traffic": traffic, "traffic_unit": "bytes/launch (FETCH_SIZE+WRITE_SIZE)",
+                    "traffic_source": traffic_src, "flops_per_launch": f_launch, "launch_us": t_stage * 1e6,
+                    "peak_measured": peak_meas, "frac_of_measured": achieved / peak_meas}
+            mfma = pmc_mfma_util(a.N, t_stage)
+            if mfma is not None:
+                roof.update(mfma)
+        # the WHOLE iteration as the driver times it against the same peak: necessary flops of one full solve() iteration
+        # (76 M^3 + 2 M Mi (M + Mi)) over ms_per_step -- launch gaps and per-chunk costs included
+        roof["iteration_frac"] = f_iter * a.steps / wall / 1e12 / PEAK_FP64_MFMA_TFLOPS
+        roof["iteration_flops"] = f_iter
         out = {
             "metric": "steady-state time-steps/sec at N=256 Re=1000",
             "value": world * a.steps / wall, "unit": "steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * wall / a.steps, "reps": reps, "launch_path": launch_path,
-            "graph_iters": gi, "higher_is_better": True,
+            "solver_mode": mode, "graph_iters": gi, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"solver=spectral (SG) N={a.N} Re={a.Re:g} fp64, full solve() iteration "
                                    "(dt, 4 RK stages + BCs, change/residual norms, E/Z/P), fluid from rest",
@@ -482,24 +648,13 @@ def main():
                        "trials_per_gpu": 1, "parallelism": f"{world} independent trial(s), one per GPU"},
             "step_only_value": world * a.steps / wall_so, "step_only_ms": 1e3 * wall_so / a.steps,
             "event_ms_per_step": 1e3 * ev / a.steps,
-            "iteration_tflops": flops_per_step(a.N, True) * a.steps / wall / 1e12,
+            "iteration_tflops": f_iter * a.steps / wall / 1e12,
             "ghia": ghia_block(a.N, a.Re),
-            "roofline": {"bound": "mfma", "kernel": "stage_kernel<GP=0,LAST=0,DUMP=0> (fused RK stage)", "achieved": achieved,
-                         "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
-                         "traffic": traffic, "traffic_unit": "bytes/launch (FETCH_SIZE+WRITE_SIZE)",
-                         "traffic_source": traffic_src, "flops_per_launch": f_launch, "launch_us": t_stage * 1e6,
-                         "peak_measured": peak_meas, "frac_of_measured": achieved / peak_meas,
-                         # the WHOLE iteration against the same peak: necessary flops of one full solve() iteration
-                         # (76 M^3 + 2 M Mi (M + Mi)) over ms_per_step -- five dependent launches, gaps included
-                         "iteration_frac": flops_per_step(a.N, True) * a.steps / wall / 1e12 / PEAK_FP64_MFMA_TFLOPS,
-                         "iteration_flops": flops_per_step(a.N, True)},
+            "roofline": roof,
         }
         out["farm"] = farm
-        out["small_n"] = small_n_block(f"cuda:{local}") if world == 1 else None
-        out["cu_batch"] = cu_batch_block(f"cuda:{local}") if world == 1 else None
-        mfma = pmc_mfma_util(a.N, t_stage)
-        if mfma is not None:
-            out["roofline"].update(mfma)
+        out["small_n"] = small_n_block(f"cuda:{local}") if (world == 1 and not a.headline_only) else None
+        out["cu_batch"] = cu_batch_block(f"cuda:{local}") if (world == 1 and not a.headline_only) else None
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(a.N, a.Re)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]

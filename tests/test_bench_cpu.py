@@ -74,3 +74,28 @@ def test_one_batch_runs_in_the_callers_thread_without_a_gpu():
     import pytest
     with pytest.raises(ZeroDivisionError):
         run_concurrently(["x"], lambda b: 1 / 0)
+
+
+def test_plain_gpus_2_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` started PLAINLY (no WORLD_SIZE): the process becomes the launcher -- two ranks of itself
+    through torch.distributed.run before anything touches a GPU --, relays rank 0's one JSON line and the ranks' exit code
+    (reference model of the fan-out: scripts/hpc_submit.py:103-107, 182-200).  --dry-run keeps the GPU out of it: rendezvous on
+    127.0.0.1, barrier, max over ranks, gather, all over gloo on CPU."""
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["LDC_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["ranks_seen"] == [0, 1] and d["dry_run"] is True
+    assert abs(d["max_over_ranks_s"] - 2e-3) < 1e-12
+    # a rank that fails takes the launcher's exit code with it (--gpus 3 inside a 2-rank world is refused by every rank)
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r2 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "3", "--dry-run"], capture_output=True, text=True,
+                        env=env2, timeout=120, cwd=tmp_path)
+    assert r2.returncode != 0 and "WORLD_SIZE=2" in (r2.stderr + r2.stdout)

@@ -62,8 +62,12 @@ def main(dirs):
                 if src in e:
                     e[dst] = e[src] / e["SQ_WAVE_CYCLES"]
         out[k] = e
-    json.dump({"source": "rocprofv3 --kernel-trace --pmc <group> -- python3 tools/pmc_run.py (N=256, 64 eager "
-                         "iterations), one group per pass: {TCC_HIT_sum,TCC_MISS_sum}, FETCH_SIZE, WRITE_SIZE; "
+    for k, e in out.items():
+        if k.startswith(("wide_kernel", "xcd_kernel", "cu_kernel")):
+            e["iterations_per_launch"] = 64          # tools/pmc_run.py: the chunk it enqueues (one launch)
+    json.dump({"source": "rocprofv3 --kernel-trace --pmc <group> -- python3 tools/pmc_run.py (N=256: one launch-path iteration, "
+                         "then ONE launch of the chip-wide kernel with 64 iterations), one group per pass: "
+                         "{TCC_HIT_sum,TCC_MISS_sum}, FETCH_SIZE, WRITE_SIZE, the SQ group; "
                          "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts wide reads at half)",
                "kernels": out}, sys.stdout, indent=1)
 
