@@ -321,7 +321,9 @@ __device__ __forceinline__ double next_dt(double umax, double vmax, const FinalA
 struct TrialState {
   int done, iter, step, flushed, pdone, drows;
   int abort;                 // a bounded spin of a grid barrier gave up (LDC_E_SYNC): every thread leaves
+  unsigned arrive;           // chip-wide kernel: waves whose stores are drained, counted over the hand-overs of the launch
   double dt, umax, vmax;
+  double dtp;                // chip-wide kernel: the step of the iteration being closed (dt already holds the next)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -2274,10 +2276,13 @@ hipError_t copy_now(void* dst, const void* src, size_t bytes, hipMemcpyKind kind
 
 // Dynamic LDS above 64 KiB has to be enabled per kernel and device (hipFuncSetAttribute).  ONCE per device and process, under
 // the setup mutex, before the first handle of that device exists -- not at every create: a sweep creates handles in one host
-// thread while another launches the same kernels, and an attribute being rewritten under a launch that needs it (the small-N
-// trial kernel asks for 70 KB, the stage kernels for up to 107 KB) ended the process with a hardware exception once in a
-// while (round 3: tests/test_fsg.py::test_gpu_config5_shape_batched_fsg_vs_oracle aborted in two full-suite runs, never alone
-// and never with the runtime's logging on -- and quite possibly what round 2 met before its captures were serialised).
+// thread while another launches the same kernels (the small-N trial kernel asks for 70 KB, the stage kernels for up to 107 KB).
+// Round 3's full GPU suite ended with "Fatal Python error: Aborted" twice at the two-thread test
+// tests/test_fsg.py::test_gpu_config5_shape_batched_fsg_vs_oracle (profiles/r03_abort_{o,r}_gpu_tests.log: the Python frames
+// of both threads, no runtime or HSA message) while every create still rewrote the attributes; the cause is INFERRED from that
+// and from the aborts stopping with this change, not read off a fault record.  ldc_attribute_rounds() counts the rounds so a
+// test can hold the library to "once per device" (tests/test_gpu_batched.py).
+int g_attr_rounds = 0;
 bool g_attrs_done[64] = {};
 int ensure_kernel_attributes() {
   std::lock_guard<std::mutex> lock(g_setup_mutex);
@@ -2290,6 +2295,7 @@ int ensure_kernel_attributes() {
       (e = enable_cu_lds()) != 0 || (e = enable_wide_lds()) != 0)
     return e;
   g_attrs_done[dev] = true;
+  ++g_attr_rounds;
   return 0;
 }
 
@@ -2539,6 +2545,11 @@ int ldc_solver_status(ldc_solver* s) {
   uint32_t flag = 0;
   HIP_TRY(copy_now(&flag, s->p.sync + LDC_SYNC_GIVEUP, sizeof(flag), hipMemcpyDeviceToHost));
   return flag ? LDC_E_SYNC : 0;
+}
+
+int ldc_attribute_rounds(void) {
+  std::lock_guard<std::mutex> lock(g_setup_mutex);
+  return g_attr_rounds;
 }
 
 int ldc_device_info(int* n_cus, int* n_xcds) {

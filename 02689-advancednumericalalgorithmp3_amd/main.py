@@ -63,6 +63,8 @@ def make_record(cfg: dict, solver, out_dir: Path, t0: float) -> dict:
                params=solver.params.to_mlflow(), metrics=solver.metrics.to_mlflow(),
                validation_errors=errors, objective=objective, objective_kind=objective_kind,
                validation_table=solver.validation_table(), total_seconds=time.perf_counter() - t0)
+    if hasattr(solver, "kernel_mode"):          # which of the library's kernels advanced this trial (include/ldc_hip.h: 0, 3, 4, 5)
+        rec["kernel_mode"] = int(solver.kernel_mode)
     if int(cfg["Re"]) in V.GHIA_RE:
         rec["ghia"] = solver.ghia_error()
     m = solver.metrics
@@ -105,6 +107,18 @@ def run_solver(cfg: dict, out_dir: Path, device: str = None) -> dict:
     return rec
 
 
+def _device_cus(device: str = None) -> int:
+    """Compute units of the device the batches will run on, as the LIBRARY counts them (ldc_device_info: the same number
+    its co-resident kernels size their launches by; nothing is asked of torch's device bookkeeping)."""
+    import ctypes
+    import torch
+    from solvers.spectral import ldc_lib as L
+    cus, xcds = ctypes.c_int(), ctypes.c_int()
+    with torch.cuda.device(torch.device(device if device is not None else "cuda")):
+        L.check(L.lib().ldc_device_info(ctypes.byref(cus), ctypes.byref(xcds)), "ldc_device_info")
+    return int(cus.value)
+
+
 def run_batches(groups: list, device: str = None) -> list:
     """groups: [(cfgs, out_dirs)], each a set of SG (or FSG) trials of equal N that can share their launches.
     Returns the record lists in the same order.
@@ -118,7 +132,7 @@ def run_batches(groups: list, device: str = None) -> list:
     import threading
     from solvers.spectral.batched import BatchedFSGSolver, BatchedSGSolver, run_concurrently
     n_workers = max(1, int(os.environ.get("LDC_BATCH_STREAMS", "3")))
-    n_cus = 256              # an MI355X; only decides whether a size fills the chip on its own (N >= 241) -- no device query here
+    n_cus = _device_cus(device)      # decides whether a size fills the chip on its own (N >= 241 on 256 CUs)
     tasks = []
     for gi, (cfgs, _) in enumerate(groups):
         parts = max(1, min(2, n_workers, len(cfgs)))      # halves: more, smaller batches measured no better (N=128)
@@ -333,10 +347,15 @@ def main(argv=None) -> float | None:
     space, fixed = C.sweep_space(base_cfg, cli_values, multirun)
     search = {k: v for k, v in space.items() if isinstance(v, C.Interval)}
     dist = Dist().init()
-    device = None
+    device, shared_card = None, False
     if dist.world > 1:          # one GPU per rank; ranks beyond the visible cards share them (tests: 2 ranks, 1 card)
         import torch
-        device = f"cuda:{dist.local_rank % max(1, torch.cuda.device_count())}"
+        n_cards = max(1, torch.cuda.device_count())
+        device = f"cuda:{dist.local_rank % n_cards}"
+        shared_card = int(os.environ.get("LOCAL_WORLD_SIZE", dist.world)) > n_cards
+        if shared_card:
+            log.warning("%d ranks on %d visible GPU(s): ranks share cards, every trial takes the launch path "
+                        "(solver.persistent=0)", dist.world, n_cards)
 
     stamp_cfg = C.resolve(C.compose_job(composer, overrides, fixed))
     hy = stamp_cfg.get("hydra", {})
@@ -348,10 +367,29 @@ def main(argv=None) -> float | None:
     batch_cap_given = "LDC_MAX_BATCH" in os.environ or "batch_trials" in (stamp_cfg.get("hydra", {}).get("launcher", {}) or {})
     max_batch = int(os.environ.get("LDC_MAX_BATCH", stamp_cfg.get("hydra", {}).get("launcher", {}).get("batch_trials", 64)))
 
+    # Which kernel advances a trial depends, in auto mode, on the size AND on how many trials share its batch (batched.py);
+    # the kernels agree to rounding, so an iteration count at the stopping threshold can move by one with LDC_MAX_BATCH, the
+    # world size or the search-round size.  A study that must not depend on those pins ONE mode for every trial whose
+    # configuration leaves the choice open (solver.persistent = -1): LDC_PIN_MODE=0 (launch path) or 3 (one XCD per trial
+    # where the size fits, the launch path above); search_mode=reference pins 3.  Ranks that share a card (more ranks than
+    # visible GPUs) get 0: co-resident launches of two PROCESSES cannot be kept apart by ldc_lib.resident_lock.
+    sw0 = stamp_cfg.get("hydra", {}).get("sweeper", {}) or {}
+    pin_mode = os.environ.get("LDC_PIN_MODE")
+    if pin_mode is None and search and str(os.environ.get("LDC_SEARCH_MODE", sw0.get("search_mode", "throughput"))).lower() == "reference":
+        pin_mode = 3
+    if shared_card:
+        pin_mode = 0
+    if pin_mode is not None and int(pin_mode) not in (0, 3):
+        raise ValueError(f"LDC_PIN_MODE={pin_mode}: 0 (launch path) or 3 (one XCD per trial where it fits)")
+
     def job_cfg(assignment, index):
         cfg = C.compose_job(composer, overrides, list(fixed) + list(assignment))
         cfg.setdefault("hydra", {}).setdefault("job", {})["num"] = index
-        return C.resolve(cfg)
+        cfg = C.resolve(cfg)
+        sv = cfg.get("solver") or {}
+        if pin_mode is not None and str(sv.get("_target_", "")) in (SG, FSG) and (int(sv.get("persistent", -1)) == -1 or shared_card):
+            sv["persistent"] = int(pin_mode)
+        return cfg
 
     def run_group(items, jobs, offset=0):
         """items: [(index, trial)] owned by this rank with one group key.  Trials that can share their launches
@@ -410,8 +448,8 @@ def main(argv=None) -> float | None:
 
     solver_hint = str((stamp_cfg.get("solver") or {}).get("_target_", ""))
 
-    def cost_of(trial):          # expected GPU seconds (measured iteration counts x time per iteration, by solver class)
-        return trial_cost(dict({"Re": stamp_cfg.get("Re", 100)}, **trial), solver=solver_hint)
+    def cost_of(trial, batch=1):     # expected GPU seconds (measured iteration counts x time per iteration, by solver class and batch size)
+        return trial_cost(dict({"Re": stamp_cfg.get("Re", 100)}, **trial), solver=solver_hint, batch=batch)
 
     global _TRACKER
     _TRACKER = None

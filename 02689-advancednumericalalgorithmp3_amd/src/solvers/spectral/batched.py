@@ -5,7 +5,14 @@ conf/machine/local.yaml:5-9, conf/experiment/optimization/corner_smoothing.yaml:
 occupies 64 of the 256 CUs of an MI355X (one 16x16 tile per work-group), an N=64 trial 16, an N=32 trial 4;
 batching B trials into every launch (``blockIdx.y`` = trial) fills the chip and amortises the per-launch
 fixed cost.  Each trial keeps its own state, Re / lid profile / tolerance, dt, latch and history, so results
-are bit-identical to running the trials one after another (tests/test_gpu_batched.py).
+are bit-identical to running the trials one after another WITH THE SAME KERNEL (tests/test_gpu_batched.py).
+Which kernel that is -- ``kernel_mode``: 0 the launch path, 3 one XCD per trial, 4 one CU per trial -- depends in
+auto mode (``persistent=-1``) on the size and on how many trials share the batch (mode 4 from 80 trials, 32 at
+N=32; a lone N>=80 trial takes mode 5, a batch of them the launch path).  The kernels agree to rounding
+(<= 1e-12 over a fixture trajectory), not bit for bit, so an iteration count at the stopping threshold can move
+by one with the batch size.  Every trial's ``results.json`` carries ``kernel_mode``; a study that must not depend
+on batch size, world size or search-round size pins one (``LDC_PIN_MODE=0|3``, or ``search_mode=reference``
+which pins 3: one XCD per trial where the size fits, the launch path above).
 """
 from __future__ import annotations
 
@@ -27,6 +34,7 @@ LATCH_CAPPED = 3      # ctrl[DONE] code set by the host when a trial of a batch 
 
 class BatchedSGSolver:
     """``trials``: list of SGSolver keyword dicts with identical nx/ny (and device)."""
+    kernel_mode = -1          # set when the batch handle exists (_ensure_batch)
 
     def __init__(self, trials: list):
         if not trials:
@@ -74,6 +82,11 @@ class BatchedSGSolver:
             L.check(lib.ldc_batch_create(arr, B, base, nbytes, C.byref(h)), "ldc_batch_create")
         self._batch = h
         self._batch_keys = [s._handle_key for s in self.solvers]
+        # which kernel advances these trials (0 launch path, 3 one XCD per trial, 4 one CU per trial): in auto mode that
+        # depends on the size AND on how many trials share the batch -- every trial's record says which it was
+        self.kernel_mode = int(lib.ldc_batch_mode(h))
+        for s in self.solvers:
+            s.kernel_mode = self.kernel_mode
 
     def close_batch(self):
         if self._batch is not None:
@@ -142,7 +155,7 @@ class BatchedSGSolver:
         def words(key):
             return torch.stack([s.d[key] for s in self.solvers]).cpu().numpy()
         starts = [int(x) for x in words("ctrl")[:, L.CTRL_ITER]]
-        resident = int(n_iters) > 1 and all(L.lib().ldc_solver_mode(s._handle) in (3, 4) for s in self.solvers)
+        resident = int(n_iters) > 1 and self.kernel_mode in (3, 4)
         lock = L.resident_lock(dev.index or 0) if resident else contextlib.nullcontext()
         with lock, torch.cuda.device(dev):        # (see ldc_lib.resident_lock: co-resident launches one at a time per device)
             L.check(L.lib().ldc_batch_enqueue(self._batch, int(n_iters), int(bool(diagnostics)), L.stream_ptr(dev)),
@@ -257,7 +270,9 @@ class BatchedFSGSolver:
             outs[k] = b.run_to_tolerance(parts[k][1], parts[k][2], diagnostics=False)
             b.close_batch()
 
-        run_concurrently([0, 1], run, group[0].device, first_stream=8)      # (streams of their own: not the pool's)
+        # streams of their own, not the pool's -- and not another pool worker's either: two FSG groups splitting a level at
+        # the same time would otherwise take turns on one pair
+        run_concurrently([0, 1], run, group[0].device, first_stream=8 + 2 * int(getattr(_WORKER, "index", 0)))
         return outs[0] + outs[1]
 
     def solve(self, max_iter: int = None):
@@ -304,6 +319,8 @@ class BatchedFSGSolver:
 
 
 _WORKER_STREAMS = {}      # (device index, worker) -> torch.cuda.Stream, see run_concurrently
+_WORKER_STREAMS_LOCK = __import__("threading").Lock()      # (several pool workers may ask for nested streams at once)
+_WORKER = __import__("threading").local()                  # .index: which worker of run_concurrently this thread is (0 outside)
 
 
 def run_concurrently(batches: list, fn, device=None, first_stream: int = 0) -> float:
@@ -331,19 +348,21 @@ def run_concurrently(batches: list, fn, device=None, first_stream: int = 0) -> f
     streams = []
     for k in range(len(batches)):
         key = (dev.index, first_stream + k)      # (first_stream: a nested use -- the levels of a batched FSG solve -- keeps off the pool's)
-        if key not in _WORKER_STREAMS:
-            with torch.cuda.device(dev):
-                least, greatest = C.c_int(), C.c_int()
-                L.check(L.lib().ldc_stream_priority_range(C.byref(least), C.byref(greatest)), "ldc_stream_priority_range")
-                levels = [0, greatest.value, least.value]               # normal, high, low
-                handle = C.c_void_p()
-                L.check(L.lib().ldc_stream_create(levels[k % 3], C.byref(handle)), "ldc_stream_create")
-            _WORKER_STREAMS[key] = torch.cuda.ExternalStream(handle.value, device=dev)      # kept for the process' life
-        streams.append(_WORKER_STREAMS[key])
+        with _WORKER_STREAMS_LOCK:
+            if key not in _WORKER_STREAMS:
+                with torch.cuda.device(dev):
+                    least, greatest = C.c_int(), C.c_int()
+                    L.check(L.lib().ldc_stream_priority_range(C.byref(least), C.byref(greatest)), "ldc_stream_priority_range")
+                    levels = [0, greatest.value, least.value]               # normal, high, low
+                    handle = C.c_void_p()
+                    L.check(L.lib().ldc_stream_create(levels[k % 3], C.byref(handle)), "ldc_stream_create")
+                _WORKER_STREAMS[key] = torch.cuda.ExternalStream(handle.value, device=dev)      # kept for the process' life
+            streams.append(_WORKER_STREAMS[key])
     errors = [None] * len(batches)
 
     def work(k):
         try:
+            _WORKER.index = first_stream + k
             with torch.cuda.device(dev), torch.cuda.stream(streams[k]):
                 streams[k].wait_stream(here)          # the solvers were built (uploads, packing) on the caller's stream
                 fn(batches[k])

@@ -86,6 +86,7 @@ def lib() -> C.CDLL:
     L.ldc_solver_set_persistent.argtypes = [_dp, C.c_int]
     L.ldc_solver_status.argtypes = [_dp]
     L.ldc_device_info.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ldc_attribute_rounds.argtypes = []
     L.ldc_solver_mode.argtypes = [_dp]
     L.ldc_batch_mode.argtypes = [_dp]
     L.ldc_stage.argtypes = [_dp, C.c_int, _dp]
@@ -124,7 +125,7 @@ def lib() -> C.CDLL:
 EXPORTS = (
     "ldc_version", "ldc_error_string", "ldc_device_check", "ldc_solver_create", "ldc_solver_destroy",
     "ldc_stage", "ldc_pressure_transform", "ldc_diagnostics", "ldc_finalize", "ldc_prime", "ldc_global_quantities",
-    "ldc_solver_enqueue", "ldc_solver_set_graph_iters", "ldc_solver_set_persistent", "ldc_solver_status", "ldc_solver_mode", "ldc_batch_mode", "ldc_device_info",
+    "ldc_solver_enqueue", "ldc_solver_set_graph_iters", "ldc_solver_set_persistent", "ldc_solver_status", "ldc_solver_mode", "ldc_batch_mode", "ldc_device_info", "ldc_attribute_rounds",
     "ldc_residual_debug", "ldc_gemm_nt",
     "ldc_batch_workspace_bytes", "ldc_batch_create", "ldc_batch_destroy", "ldc_batch_enqueue",
     "ldc_poisson_fastdiag", "ldc_vortex_extrema", "ldc_vortex_extrema_xy", "ldc_mfma_selftest", "ldc_mfma_peak", "ldc_debug_ablate", "ldc_debug_stamps",

@@ -346,6 +346,7 @@ class SGSolver(LidDrivenCavitySolver):
             if rc == -1 and mode in (3, 4, 5):
                 rc = L.lib().ldc_solver_set_persistent(h, 0)
             L.check(rc, "ldc_solver_set_persistent")
+            self.kernel_mode = int(L.lib().ldc_solver_mode(h))       # (a batch overwrites it with ITS mode: batched.py)
         except Exception:
             self.close()
             self._handle_key = None

@@ -19,15 +19,26 @@ import numpy as np
 log = logging.getLogger(__name__)
 
 
-# Measured on one MI355X (profiles/r02_sweeps_streams.md, BASELINE config 4 at full size, reference stopping rule):
-# iterations to the reference's convergence criterion and microseconds per full iteration of a lone trial.
+# Measured on one MI355X.  Iterations to the reference's convergence criterion: BASELINE config 4 at full size
+# (profiles/r02_sweeps_streams.md).  Microseconds per full iteration (with E / Z / P) by the kernel a trial really gets:
+#   * a LONE trial: the one-XCD kernel up to N = 79 (profiles/r03_xcd_ab.log: N=16 10.8, 32 12.5, 64 16.9 -- the launch path it
+#     replaced took 28.6 / 29.6 / 30.6), the chip-wide kernel from N = 80 (profiles/r04_wide_ab_*.log: N=128 26.1, 256 35.1;
+#     launch path 35.7 / 50.2);
+#   * a trial INSIDE a batch of equal-N trials (>= 8 of them; 1e6 / trial-iterations per second): N=16 and 32 on the
+#     trial-per-CU / one-XCD kernels (profiles/r03_cu_ab.log: 64 trials 5.7 M/s and 3.2 M/s), N=64 eight per launch on the
+#     one-XCD kernel (r03_xcd_ab.log: 467.6 k/s), N=128 two halves of eight on two streams of the launch path (BENCH_r03 farm:
+#     131.3 k/s), N=256 two trials on two streams (23.4 k/s).
+# The smoother (FSG levels: no E / Z / P, the pressure transformed every stage): r03_xcd_ab.log, r04_wide_ab_*.log.
 _SG_ITERATIONS = {(64, 100): 306441, (64, 400): 273012, (64, 1000): 247661,
                   (128, 100): 656077, (128, 400): 895532, (128, 1000): 832853,
                   (256, 100): 1050762, (256, 400): 1088448, (256, 1000): 1299041}
-_US_PER_ITERATION = {16: 26.0, 32: 26.5, 64: 31.8, 128: 38.3, 256: 52.8}      # SG, launch path, with E/Z/P
+_US_PER_ITERATION = {16: 10.8, 32: 12.5, 64: 16.9, 128: 26.1, 256: 35.1}               # SG, lone trial
+_US_PER_ITERATION_BATCHED = {16: 0.175, 32: 0.31, 64: 2.14, 128: 7.6, 256: 42.7}       # SG, per trial of a batch
+_US_PER_SMOOTHER_ITERATION = {16: 10.5, 32: 11.7, 64: 16.1, 128: 29.1, 256: 71.4}      # FSG level, lone (N=256: launch path)
+_US_PER_SMOOTHER_ITERATION_BATCHED = {16: 0.32, 32: 0.81, 64: 2.14, 128: 12.2, 256: 68.0}
+_BATCH_FULL = 8                       # from this many equal-N trials on a GPU the batched figure applies; between 1 and it: linear in 1/B
 _FSG_COARSE_ITERATIONS = 250_000      # config 5 (N=128, Re=1000): the 64-level takes ~250 k iterations, the 128-level ~35 k
-_FSG_FINE_ITERATIONS = 35_000
-_SMOOTHER_LAUNCH_FACTOR = 8.0 / 5.0   # smoother mode: eight launches per iteration instead of five
+_FSG_FINE_ITERATIONS = 35_000         # (profiles/r03_sweeps.md: 64 trials, 18.36 M trial-iterations, 68 s on one GPU)
 
 
 def _interp_log(table: dict, x: float) -> float:
@@ -46,11 +57,22 @@ def _interp_log(table: dict, x: float) -> float:
     return float(table[lo] * (x / lo) ** slope)
 
 
-def us_per_iteration(n: float) -> float:
-    """Microseconds per iteration of one SG trial of order n (beyond N=256 a stage is MFMA-bound: ~N^3)."""
-    if n > 256:
-        return _US_PER_ITERATION[256] * (n / 256.0) ** 3
-    return _interp_log(_US_PER_ITERATION, max(n, 16.0))
+def us_per_iteration(n: float, batch: int = 1, smoother: bool = False) -> float:
+    """Microseconds per iteration of one SG trial of order n (beyond N=256 a stage is MFMA-bound: ~N^3) that shares its
+    GPU with ``batch`` - 1 other trials of the same order; ``smoother``: an FSG level."""
+    lone, full = ((_US_PER_SMOOTHER_ITERATION, _US_PER_SMOOTHER_ITERATION_BATCHED) if smoother
+                  else (_US_PER_ITERATION, _US_PER_ITERATION_BATCHED))
+
+    def at(table):
+        if n > 256:
+            return table[256] * (n / 256.0) ** 3
+        return _interp_log(table, max(n, 16.0))
+
+    b = max(1, min(int(batch), _BATCH_FULL))
+    if b == 1:
+        return at(lone)
+    w = (1.0 - 1.0 / b) / (1.0 - 1.0 / _BATCH_FULL)          # 0 for a lone trial, 1 from _BATCH_FULL trials
+    return (1.0 - w) * at(lone) + w * at(full)
 
 
 def expected_iterations(n: float, re: float) -> float:
@@ -60,12 +82,12 @@ def expected_iterations(n: float, re: float) -> float:
     return _interp_log({k: v for (k, rr), v in _SG_ITERATIONS.items() if rr == r}, max(n, 8.0))
 
 
-def trial_cost(trial: dict, solver: str = None) -> float:
+def trial_cost(trial: dict, solver: str = None, batch: int = 1) -> float:
     """Expected GPU seconds of a trial, for longest-first scheduling: measured iteration counts (N, Re) times the
-    measured time per iteration (N), by solver class -- an FSG trial is its coarse level plus a short fine level
-    in smoother mode.  (Round 2 used N^5, which ignores Re and the solver class: the N=256, Re=1000 trial of config 4
-    is 1.3 M iterations, the N=256, Re=100 one 1.05 M.)  ``solver``: class hint ("fsg" in it selects the FSG model);
-    a trial's own "solver" entry wins."""
+    measured time per iteration (N, and how many equal-N trials share the GPU: ``batch``), by solver class -- an FSG
+    trial is its coarse level plus a short fine level in smoother mode.  (Round 2 used N^5, which ignores Re and the
+    solver class; round 3 launch-path times only, which weighed an N=64 trial 2x too heavy against N=256.)
+    ``solver``: class hint ("fsg" in it selects the FSG model); a trial's own "solver" entry wins."""
     t = dict(trial)
     n, re = float(t.get("N", 32)), float(t.get("Re", 100))
     kind = str(t.get("solver", solver or "")).lower()
@@ -74,12 +96,12 @@ def trial_cost(trial: dict, solver: str = None) -> float:
         cost, m = 0.0, n
         for lvl in range(levels):
             its = _FSG_FINE_ITERATIONS if lvl == 0 and levels > 1 else _FSG_COARSE_ITERATIONS
-            cost += its * us_per_iteration(m) * _SMOOTHER_LAUNCH_FACTOR
+            cost += its * us_per_iteration(m, batch, smoother=True)
             if m // 2 < 12:
                 break
             m //= 2
         return cost * 1e-6
-    return expected_iterations(n, re) * us_per_iteration(n) * 1e-6
+    return expected_iterations(n, re) * us_per_iteration(n, batch) * 1e-6
 
 
 def plan_rounds(n_trials: int, n_jobs: int, world: int, per_gpu: int = None, mode: str = "throughput",
@@ -188,7 +210,16 @@ def run_farm(trials: list, run_trial, dist: Dist, cost=trial_cost, run_group=Non
     ``{"error": repr(exc), "objective": inf}``, every rank still reaches the gather, and afterwards
     ``FarmError`` (carrying all records) is raised on all ranks alike unless ``raise_on_error`` is false --
     like the reference's joblib / Optuna launchers, which surface the exception and keep finished trials."""
-    owner = assign_lpt([cost(t) for t in trials], dist.world)
+    # how many trials of the same order a GPU will see: they share their launches there, and a trial inside a batch costs a
+    # fraction of a lone one (N=64: 2.1 us per iteration instead of 16.9) -- passed to cost functions that take it
+    census = {}
+    for t in trials:
+        census[t.get("N")] = census.get(t.get("N"), 0) + 1
+    try:
+        costs = [cost(t, batch=max(1, census[t.get("N")] // dist.world)) for t in trials]
+    except TypeError:          # a caller's own cost(trial)
+        costs = [cost(t) for t in trials]
+    owner = assign_lpt(costs, dist.world)
     mine = {}
     my = [(idx, t) for idx, t in enumerate(trials) if owner[idx] == dist.rank]
     if run_group is None:

@@ -246,6 +246,9 @@ int ldc_solver_mode(ldc_solver *s);
 int ldc_solver_status(ldc_solver *s);
 /* compute units and XCDs of the current device as the library counts them (what modes 3 / 5 size their launches by) */
 int ldc_device_info(int *n_cus, int *n_xcds);
+/* how many times this process set its kernels' attributes (dynamic LDS above 64 KiB): once per device that has had a   */
+/* handle, never again at later creates -- a host with several threads relies on that                    */
+int ldc_attribute_rounds(void);
 
 /* batched trials (the sweep axis of the reference on ONE GPU): n_trials solver handles of      */
 /* identical geometry (M, LD, mode) advanced by the same launches, blockIdx.y = trial; each     */

@@ -14,14 +14,24 @@ def kw(N, Re, cs=0.15, **extra):
     return d
 
 
+def batch_mode(b):
+    from solvers.spectral import ldc_lib as L
+    return int(L.lib().ldc_batch_mode(b._batch))
+
+
+@pytest.mark.parametrize("persistent", [0, -1])
 @pytest.mark.parametrize("N", [32, 24, 64])
-def test_batched_iterations_equal_individual_runs(N):
+def test_batched_iterations_equal_individual_runs(N, persistent):
+    """persistent=0: the shared launches of the launch path (blockIdx.y = trial, batched graphs); -1: what a sweep gets by
+    default at these sizes (the one-XCD kernel, mode 3).  Both against one-after-another runs in the SAME mode."""
     from solvers.spectral.batched import BatchedSGSolver
     from solvers.spectral.sg import SGSolver
     trials = [kw(N, 100, 0.15), kw(N, 400, 0.10), kw(N, 50, 0.30, CFL=1.0), kw(N, 250, 0.05, corner_treatment="saad"),
               kw(N, 100, 0.15, beta_squared=3.0)]
+    trials = [dict(t, persistent=persistent) for t in trials]
     b = BatchedSGSolver(trials)
     recs = b.run_iterations(150)
+    assert batch_mode(b) == (0 if persistent == 0 else 3)
     for t, s, r in zip(trials, b.solvers, recs):
         one = SGSolver(**t)
         r1 = one.run_iterations(150)
@@ -162,6 +172,27 @@ def test_batch_workspace_is_not_filled_behind_the_librarys_back():
     b.close()
 
 
+def test_kernel_attributes_are_set_once_per_device_not_per_create():
+    """hipFuncSetAttribute (dynamic LDS above 64 KiB) once per device and process, before the first handle exists -- never
+    again at later creates, which may run in one host thread while another launches the same kernels (the inferred cause of
+    round 3's two silent aborts).  The library counts the rounds."""
+    from solvers.spectral import ldc_lib as L
+    from solvers.spectral.batched import BatchedSGSolver
+    from solvers.spectral.sg import SGSolver
+    one = SGSolver(**kw(24, 100.0))
+    one.run_iterations(4)
+    assert L.lib().ldc_attribute_rounds() == 1
+    for n in (16, 32, 48, 96):
+        s = SGSolver(**kw(n, 100.0))
+        s.run_iterations(4)
+        s.close()
+    b = BatchedSGSolver([kw(32, 100.0), kw(32, 200.0)])
+    b.run_iterations(8)
+    b.close()
+    one.close()
+    assert L.lib().ldc_attribute_rounds() == 1
+
+
 def test_batched_fsg_where_every_trial_diverges_on_the_coarse_level():
     """The reference's Optuna experiment samples N = 30 at Re = 1000 (conf/experiment/optimization/corner_smoothing.yaml): its
     coarse level N = 15 blows up within a few thousand iterations, the NaN latch ends the trial ("early NaN/Inf detection
@@ -208,15 +239,18 @@ def test_batched_fsg_rejects_mixed_hierarchies():
         BatchedFSGSolver([fsg_kw(32, 100), fsg_kw(32, 100, n_levels=1)])
 
 
-def test_two_halves_on_two_streams_equal_stand_alone_solves():
+@pytest.mark.parametrize("persistent", [0, -1])
+def test_two_halves_on_two_streams_equal_stand_alone_solves(persistent):
     """main.py runs a rank's equal-N trials as two batches on two HIP streams (solve_concurrently): same kernels per
     trial, so converged solves keep their iteration counts and fields bit for bit; the wall-time shares add up."""
     from solvers.spectral.batched import BatchedSGSolver, solve_concurrently
     from solvers.spectral.sg import SGSolver
     trials = [kw(32, 100, 0.15, tolerance=1e-4), kw(32, 400, 0.10, tolerance=1e-4), kw(32, 50, 0.30, tolerance=1e-4),
               kw(32, 250, 0.05, tolerance=1e-4, max_iterations=700), kw(32, 100, 0.15, tolerance=1e-4, beta_squared=3.0)]
+    trials = [dict(t, persistent=persistent) for t in trials]
     halves = [BatchedSGSolver(trials[:3]), BatchedSGSolver(trials[3:])]
     wall = solve_concurrently(halves)
+    assert all(batch_mode(b) == (0 if persistent == 0 else 3) for b in halves)
     solvers = halves[0].solvers + halves[1].solvers
     assert halves[0].batch_seconds == halves[1].batch_seconds == wall and halves[0].batch_size == 5
     assert abs(sum(s.metrics.wall_time_seconds for s in solvers) - wall) < 1e-6 * max(1.0, wall)
@@ -231,12 +265,13 @@ def test_two_halves_on_two_streams_equal_stand_alone_solves():
         b.close()
 
 
-def test_fsg_batches_on_two_streams_equal_stand_alone_solves():
+@pytest.mark.parametrize("persistent", [0, -1])
+def test_fsg_batches_on_two_streams_equal_stand_alone_solves(persistent):
     from solvers.spectral.batched import BatchedFSGSolver, solve_concurrently
     from solvers.spectral.fsg import FSGSolver
     base = dict(name="spectral_fsg", nx=32, ny=32, basis_type="chebyshev", CFL=1.5, beta_squared=5.0,
                 corner_treatment="smoothing", multigrid="fsg", n_levels=2, coarse_tolerance_factor=10.0, tolerance=1e-5,
-                max_iterations=4000, check_every=128, graph_iters=16)
+                max_iterations=4000, check_every=128, graph_iters=16, persistent=persistent)
     trials = [dict(base, Re=100.0, corner_smoothing=0.15), dict(base, Re=400.0, corner_smoothing=0.08),
               dict(base, Re=200.0, corner_smoothing=0.25)]
     halves = [BatchedFSGSolver(trials[:2]), BatchedFSGSolver(trials[2:])]
@@ -288,26 +323,32 @@ def test_batches_built_and_closed_while_another_thread_replays_graphs():
     import threading
     import torch
     from solvers.spectral.batched import BatchedSGSolver, run_concurrently
-    trials_b = [kw(32, 100, 0.15, graph_iters=8), kw(32, 400, 0.10, graph_iters=8)]
+    # persistent=0: the launch path, the only one that captures, instantiates and replays hipGraphs (in auto mode these sizes
+    # take the one-XCD kernel, whose launches ldc_lib.resident_lock serialises -- nothing of this test would be exercised)
+    trials_b = [kw(32, 100, 0.15, graph_iters=8, persistent=0), kw(32, 400, 0.10, graph_iters=8, persistent=0)]
     ref = BatchedSGSolver(trials_b)
     want = ref.run_iterations(1200, diagnostics=False)
+    assert batch_mode(ref) == 0
     ref.close()
-    got, built = {}, []
+    got, built, modes = {}, [], []
 
     def job(which):
         if which == "A":
             for k in range(6):
-                b = BatchedSGSolver([kw(24, 100 + 50 * k, 0.1, graph_iters=4), kw(24, 200, 0.2, graph_iters=4)])
+                b = BatchedSGSolver([kw(24, 100 + 50 * k, 0.1, graph_iters=4, persistent=0),
+                                     kw(24, 200, 0.2, graph_iters=4, persistent=0)])
                 b.run_iterations(16, diagnostics=(k % 2 == 0))       # capture + instantiate (both graph flavours in turn)
+                modes.append(batch_mode(b))
                 b.close()                                            # hipGraphExecDestroy under the mutex
                 built.append(k)
         else:
             b = BatchedSGSolver(trials_b)
             rows = [b.run_iterations(100, diagnostics=False) for _ in range(12)]      # replays + stream-level waits
+            modes.append(batch_mode(b))
             got["B"] = [np.concatenate([r[q] for r in rows], axis=0) for q in range(2)]
             b.close()
 
     run_concurrently(["A", "B"], job)
-    assert built == list(range(6))
+    assert built == list(range(6)) and modes == [0] * 7
     for w, g in zip(want, got["B"]):
         assert np.array_equal(w, g)

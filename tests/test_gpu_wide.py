@@ -139,3 +139,23 @@ def test_wide_and_launch_path_hand_the_state_to_each_other():
     for c in range(1, 7):
         assert rel(rec[:, c], want[:, c]) < (1e-10 if c < 5 else 1e-9), c
     s.close()
+
+
+@pytest.mark.parametrize("N,layout", [(256, "tail"), (128, "tail"), (128, "tiles"), (255, "tiles"), (200, "tiles")])
+def test_wide_two_identical_runs_agree_bit_for_bit(monkeypatch, N, layout):
+    """The chip-wide kernel is a protocol between 36 ... 256 work-groups that only meet through flags: a hole in it shows as a
+    result that depends on timing.  Two solvers with the same inputs advance side by side in chunks of five iterations; their
+    states, histories and EVERY slab of partial sums (stage-4 sums, enstrophy and palinstrophy of both parities) must be equal
+    bit for bit, 60 times over.  (Round 4: with the grad-omega contractions in the window of stage 2 the palinstrophy partials
+    of some tiles differed between two such runs in 5 % of the iterations -- the trajectory tests against the reference saw it
+    once in a few runs only.)"""
+    if layout == "tiles" and N % 16 == 0:
+        monkeypatch.setenv("LDC_WIDE_LAYOUT", "tiles")
+    A, B = make(N, 1000), make(N, 1000)
+    assert mode_of(A) == 5 and mode_of(B) == 5
+    for rep in range(60):
+        ra, rb = A.run_iterations(5), B.run_iterations(5)
+        assert np.array_equal(ra, rb), rep
+        for key in ("partials", "U", "V", "P"):
+            assert np.array_equal(A.d[key].cpu().numpy(), B.d[key].cpu().numpy()), (key, rep)
+    A.close(); B.close()

@@ -186,13 +186,30 @@ def test_trial_cost_follows_the_measured_iteration_counts():
     (profiles/r02_sweeps_streams.md); N^5 ignored Re and the solver class."""
     from utilities.sweep.farm import trial_cost, expected_iterations, us_per_iteration
     assert expected_iterations(256, 1000) == 1299041 and expected_iterations(64, 400) == 273012
-    assert trial_cost(dict(N=256, Re=1000)) == pytest.approx(1299041 * 52.8e-6)
+    assert trial_cost(dict(N=256, Re=1000)) == pytest.approx(1299041 * 35.1e-6)           # a lone trial on the chip-wide kernel (round 4)
     assert trial_cost(dict(N=256, Re=1000)) > trial_cost(dict(N=256, Re=400)) > trial_cost(dict(N=256, Re=100))
     assert trial_cost(dict(N=128, Re=400)) > trial_cost(dict(N=128, Re=1000))            # 895 k vs 833 k iterations
-    assert us_per_iteration(512) == pytest.approx(52.8 * 8) and 26.0 <= us_per_iteration(48) <= 31.8
-    assert 4.0 < trial_cost(dict(N=48, Re=250)) < trial_cost(dict(N=64, Re=250))        # interpolated, monotone in N
+    assert us_per_iteration(512) == pytest.approx(35.1 * 8) and 10.8 <= us_per_iteration(48) <= 16.9
+    assert 2.0 < trial_cost(dict(N=48, Re=250)) < trial_cost(dict(N=64, Re=250))        # interpolated, monotone in N
     fsg = trial_cost(dict(N=128, Re=1000), solver="solvers.spectral.fsg.FSGSolver")
     assert fsg < trial_cost(dict(N=128, Re=1000)) and fsg == trial_cost(dict(N=128, Re=1000, solver="spectral/fsg"))
+
+
+def test_trial_cost_is_what_the_kernels_of_round_3_and_4_measured():
+    """An N=64 trial weighs what the one-XCD kernel takes (16.9 us per iteration alone -- the launch-path figure of round 2,
+    31.8, made LPT weigh small-N trials 2x too heavy against N=256), a trial inside a batch what a batch takes per trial, and
+    config 5 (64 FSG trials at N=128, eight per round) what profiles/r03_sweeps.md measured end to end."""
+    from utilities.sweep.farm import trial_cost, us_per_iteration
+    assert trial_cost(dict(N=64, Re=100)) == pytest.approx(306441 * 16.9e-6)               # 5.2 s, not 9.7
+    assert trial_cost(dict(N=256, Re=100)) / trial_cost(dict(N=64, Re=100)) == pytest.approx(1050762 * 35.1 / (306441 * 16.9))
+    assert trial_cost(dict(N=64, Re=100), batch=8) == pytest.approx(306441 * 2.14e-6)      # eight per launch: 467.6 k trial-it/s
+    assert trial_cost(dict(N=64, Re=100), batch=64) == trial_cost(dict(N=64, Re=100), batch=8)
+    lone, two, eight = (us_per_iteration(128, b) for b in (1, 2, 8))
+    assert lone == pytest.approx(26.1) and eight == pytest.approx(7.6) and eight < two < lone
+    # config 5: 64 trials in rounds of eight on one GPU took 68 s end to end (records included): ~1.06 s per trial
+    fsg8 = trial_cost(dict(N=128, Re=1000), solver="solvers.spectral.fsg.FSGSolver", batch=8)
+    assert 0.7 < fsg8 < 1.2
+    assert trial_cost(dict(N=128, Re=1000), solver="solvers.spectral.fsg.FSGSolver") == pytest.approx((250_000 * 16.1 + 35_000 * 29.1) * 1e-6)
 
 
 def test_a_failing_unbatched_trial_costs_only_its_own_record(tmp_path, monkeypatch):

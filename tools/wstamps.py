@@ -35,15 +35,22 @@ st = buf.cpu().numpy().reshape(nwg, W, 4, P)
 L.lib().ldc_debug_stamps(s._handle, None)
 print(f"N={N} ({nwg} work-groups), {kind}: cycles (s_memtime) relative to the stage entry of wave 0 of each work-group; median [min..max] over work-groups")
 names = ["entry", "contr|fold:flags", "phase done", "barrier", "epilogue", "barrier", "sums out", "drained", "barrier", "flags seen|fold:loads", "next entry", "fold:totals"]
+tail = T * 16 + 1 == s.M
+ii, jj = np.arange(nwg) // T, np.arange(nwg) % T
+jobs = ((ii == jj) | (jj == (ii + 1) % T) | ((ii == 1) & (jj == 3))) if tail else np.zeros(nwg, bool)
+groups = [("all", np.ones(nwg, bool))] + ([("job tiles", jobs), ("other tiles", ~jobs)] if tail else [])
 for k in range(4):
     base = st[:, 0, k, 0][:, None]
     print(f"-- stage {k + 1}: length (wave 0 entry -> next entry) median {np.median(st[:, 0, k, 10] - st[:, 0, k, 0]):.0f} cycles")
-    for wv in (0, 1, 2, 4, 5, 6, 7):
-        row = []
-        for p in range(12):
-            x = st[:, wv, k, p] - base[:, 0]
-            x = x[st[:, wv, k, p] > 0]
-            row.append("-" if x.size == 0 else f"{np.median(x):.0f}[{x.min():.0f}..{x.max():.0f}]")
-        print(f"   wave {wv}: " + "  ".join(f"{n}={r}" for n, r in zip(names, row)))
+    for gname, sel in groups:
+        if len(groups) > 1:
+            print(f"  [{gname}: {int(sel.sum())}]")
+        for wv in range(8):
+            row = []
+            for p in range(12):
+                ok = sel & (st[:, wv, k, p] > 0)
+                x = (st[:, wv, k, p] - base[:, 0])[ok]
+                row.append("-" if x.size == 0 else f"{np.median(x):.0f}[{x.min():.0f}..{x.max():.0f}]")
+            print(f"   wave {wv}: " + "  ".join(f"{n}={r}" for n, r in zip(names, row)))
 tot = st[:, 0, 3, 10] - st[:, 0, 0, 0]
 print(f"iteration (stage 1 entry -> stage 4 exit): median {np.median(tot):.0f} cycles")
