@@ -2691,7 +2691,21 @@ int ldc_solver_enqueue(ldc_solver* s, int n_iters, int with_diag, void* stream) 
 
 size_t ldc_batch_workspace_bytes(int n_trials) { return n_trials > 0 ? batch_bytes(n_trials) : 0; }
 
-int ldc_batch_create(ldc_solver* const* solvers, int n_trials, void* workspace, size_t workspace_bytes,
+// The library's private stream behind everything `stream` holds at this moment: an event recorded there, waited for here.
+hipError_t order_setup_behind(hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_setup_mutex);
+  hipStream_t st = nullptr;
+  hipError_t e = setup_stream(&st);
+  if (e != hipSuccess) return e;
+  hipEvent_t ev = nullptr;
+  if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return e;
+  e = hipEventRecord(ev, stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(st, ev, 0);
+  const hipError_t d = hipEventDestroy(ev);      // (released by the runtime once the wait has been served)
+  return e != hipSuccess ? e : d;
+}
+
+int ldc_batch_create(ldc_solver* const* solvers, int n_trials, void* workspace, size_t workspace_bytes, void* stream,
                      ldc_batch** out) {
   if (!solvers || !out || !workspace || n_trials < 1 || n_trials > 4096) return LDC_E_ARG;
   if (workspace_bytes < batch_bytes(n_trials) || (reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return LDC_E_ARG;
@@ -2708,6 +2722,10 @@ int ldc_batch_create(ldc_solver* const* solvers, int n_trials, void* workspace, 
       return LDC_E_ARG;
   }
   { int e = on_own_device(s0); if (e) return e; if ((e = ensure_kernel_attributes()) != 0) return e; }
+  // The argument blocks go into the caller's workspace by copies on the library's own stream: whatever the caller's stream still
+  // holds for that memory (a fill that zeroes it, queued behind another worker's long launch, once wiped the blocks: round 3)
+  // comes first -- by an event, not by a rule for the caller.
+  HIP_TRY(order_setup_behind(static_cast<hipStream_t>(stream)));
   ldc_batch* b = new (std::nothrow) ldc_batch;
   if (!b) return LDC_E_STATE;
   b->B = n_trials;

@@ -68,18 +68,17 @@ class BatchedSGSolver:
         B = len(self.solvers)
         nbytes = lib.ldc_batch_workspace_bytes(B)
         dev = self.solvers[0].device
-        # The library fills the workspace by synchronous copies on a stream of its own: nothing of OURS may still be on its way
-        # into that memory.  (It used to be torch.zeros: a fill kernel queued on this thread's stream.  Behind a long launch of
-        # another worker -- a chunk of the small-N or trial-per-CU kernel holds the chip for tens of milliseconds -- the fill ran
-        # AFTER the library's copies and wiped the argument blocks: the batch's kernels then read null pointers, "memory access
-        # fault on address (nil)" in a 600-trial search round; never seen while every launch was short.)
-        self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
-        torch.cuda.current_stream(dev).synchronize()
+        # The library fills the workspace by synchronous copies on a stream of its own, which it first makes wait for THIS stream
+        # (ldc_batch_create's stream argument, ABI 7).  (The workspace used to be torch.zeros: a fill kernel queued on this
+        # thread's stream.  Behind a long launch of another worker -- a chunk of the small-N or trial-per-CU kernel holds the chip
+        # for tens of milliseconds -- the fill ran AFTER the library's copies and wiped the argument blocks: the batch's kernels
+        # then read null pointers, "memory access fault on address (nil)" in a 600-trial search round.)
+        self._ws = self._alloc_workspace(nbytes + 256, dev)
         base = (self._ws.data_ptr() + 255) & ~255
         arr = (C.c_void_p * B)(*[s._handle for s in self.solvers])
         h = C.c_void_p()
         with torch.cuda.device(dev):
-            L.check(lib.ldc_batch_create(arr, B, base, nbytes, C.byref(h)), "ldc_batch_create")
+            L.check(lib.ldc_batch_create(arr, B, base, nbytes, L.stream_ptr(dev), C.byref(h)), "ldc_batch_create")
         self._batch = h
         self._batch_keys = [s._handle_key for s in self.solvers]
         # which kernel advances these trials (0 launch path, 3 one XCD per trial, 4 one CU per trial): in auto mode that
@@ -87,6 +86,11 @@ class BatchedSGSolver:
         self.kernel_mode = int(lib.ldc_batch_mode(h))
         for s in self.solvers:
             s.kernel_mode = self.kernel_mode
+
+    @staticmethod
+    def _alloc_workspace(nbytes, dev):
+        import torch
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)      # (nothing queued: the library overwrites what it needs)
 
     def close_batch(self):
         if self._batch is not None:

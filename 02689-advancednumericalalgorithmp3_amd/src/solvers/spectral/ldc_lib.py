@@ -98,7 +98,7 @@ def lib() -> C.CDLL:
     L.ldc_solver_enqueue.argtypes = [_dp, C.c_int, C.c_int, _dp]
     L.ldc_batch_workspace_bytes.argtypes = [C.c_int]
     L.ldc_batch_workspace_bytes.restype = C.c_size_t
-    L.ldc_batch_create.argtypes = [C.POINTER(_dp), C.c_int, _dp, C.c_size_t, C.POINTER(_dp)]
+    L.ldc_batch_create.argtypes = [C.POINTER(_dp), C.c_int, _dp, C.c_size_t, _dp, C.POINTER(_dp)]
     L.ldc_batch_destroy.argtypes = [_dp]
     L.ldc_batch_enqueue.argtypes = [_dp, C.c_int, C.c_int, _dp]
     L.ldc_residual_debug.argtypes = [_dp, C.c_int, C.POINTER(_dp), _dp]

@@ -254,12 +254,13 @@ int ldc_attribute_rounds(void);
 /* identical geometry (M, LD, mode) advanced by the same launches, blockIdx.y = trial; each     */
 /* keeps its own state, dt, latch and history.  `workspace` = caller-owned DEVICE memory,        */
 /* 256-byte aligned, at least ldc_batch_workspace_bytes(n_trials) bytes, alive as long as the    */
-/* batch; it receives the per-trial kernel argument blocks (one synchronous copy at creation,    */
-/* on a stream of the library's own: NO work of the caller that writes this memory -- not even   */
-/* a fill that zeroes it -- may be pending on any stream when ldc_batch_create is called).         */
+/* batch; it receives the per-trial kernel argument blocks by synchronous copies on a stream of  */
+/* the library's own, which first waits (an event) for everything `stream` -- the stream the     */
+/* caller last used on that memory and will launch the batch on -- holds at the time of the call */
+/* (since ABI 7; until then it was the caller's duty to have nothing pending there).             */
 typedef struct ldc_batch ldc_batch;
 size_t ldc_batch_workspace_bytes(int n_trials);
-int ldc_batch_create(ldc_solver *const *solvers, int n_trials, void *workspace, size_t workspace_bytes,
+int ldc_batch_create(ldc_solver *const *solvers, int n_trials, void *workspace, size_t workspace_bytes, void *stream,
                      ldc_batch **out);
 int ldc_batch_destroy(ldc_batch *b);
 /* n_iters iterations of base.py:243-313 for every trial that is not latched yet                 */

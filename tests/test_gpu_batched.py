@@ -156,17 +156,20 @@ def test_batched_fsg_equals_individual_fsg_solves():
 def test_batch_workspace_is_not_filled_behind_the_librarys_back():
     """ldc_batch_create copies the argument blocks into the caller's workspace on a stream of its own.  The workspace used to
     be a torch.zeros tensor: behind a long launch of another worker thread the fill kernel ran AFTER those copies, wiped the
-    blocks, and the batch's kernels read null pointers (a memory access fault in a 600-trial search round).  The batch must
-    leave nothing of its own pending on the stream when it hands the workspace over -- checked without provoking the fault:
-    a long sleep is queued in front, and the stream is idle when the batch exists."""
+    blocks, and the batch's kernels read null pointers (a memory access fault in a 600-trial search round).  Since ABI 7 the
+    library itself makes its stream wait for the caller's (an event) before it copies -- checked without provoking the fault: a
+    long sleep AND a fill of the workspace-to-be are queued in front on this stream, and when the batch exists the stream is
+    idle and the blocks are intact (the batch runs)."""
     import torch
     from solvers.spectral.batched import BatchedSGSolver
     b = BatchedSGSolver([kw(32, 100.0), kw(32, 200.0)])
+    b._alloc_workspace = lambda nbytes, dev: torch.zeros(nbytes, dtype=torch.uint8, device=dev)     # the fill of round 3
     torch.cuda.synchronize()
-    torch.cuda._sleep(200_000_000)                    # ~0.1 s of an idle kernel on this stream
+    torch.cuda._sleep(200_000_000)                    # ~0.1 s of an idle kernel on this stream, the fill queues behind it
     assert not torch.cuda.current_stream().query()
     b._ensure_batch([0.0, 0.0])
-    assert torch.cuda.current_stream().query()        # whatever the batch queued for its workspace has been waited for
+    assert torch.cuda.current_stream().query()        # the library waited for this stream before it copied, and for its copies
+    assert int(torch.count_nonzero(b._ws)) > 0        # ... so the fill did not come last: the argument blocks are there
     rec = b.run_iterations(40)
     assert np.all(np.isfinite(rec[0])) and np.all(np.isfinite(rec[1]))
     b.close()

@@ -125,7 +125,9 @@ def test_two_rank_farm_on_the_gpu(tmp_path):
     """The N > 1 path on real kernels: two ranks of torch.distributed.run (gloo for the gather -- RCCL needs a GPU per
     rank and the test box has one; both ranks compute on cuda:0) run a 3 x 2 grid sweep through main.py.  Every rank
     advances ITS equal-N trials as one batch, the gathered records are complete, in grid order, and equal a
-    single-process run of the same sweep bit for bit."""
+    single-process run of the same sweep bit for bit.  Ranks that share a card take the launch path (co-resident launches of
+    two PROCESSES cannot be kept apart by a lock in one of them: main.py), so the single process is pinned to it too
+    (LDC_PIN_MODE=0) -- every record says which kernel advanced it."""
     import os
     import socket
     import subprocess
@@ -139,15 +141,16 @@ def test_two_rank_farm_on_the_gpu(tmp_path):
            "127.0.0.1", "--master-port", str(port), str(PKG / "main.py")] + argv
     r = subprocess.run(cmd, cwd=two, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    r1 = subprocess.run([sys.executable, str(PKG / "main.py")] + argv, cwd=one, env=env, capture_output=True, text=True,
-                        timeout=600)
+    r1 = subprocess.run([sys.executable, str(PKG / "main.py")] + argv, cwd=one, env=dict(env, LDC_PIN_MODE="0"),
+                        capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr[-3000:]
     load = lambda d: json.loads(next(d.glob("hydra_outputs/multirun/*/*/sweep_results.json")).read_text())   # noqa: E731
     a, b = load(two), load(one)
     assert [(x["N"], x["Re"]) for x in a] == [(n, re) for n in (32, 48) for re in (100, 400, 250, 50)]
     assert {x["rank"] for x in a} == {0, 1} and all(x["solve_group_size"] == 2 for x in a)     # two of either size per rank
-    assert all(y["solve_group_size"] == 4 and y["solve_batch_size"] == 4 for y in b)           # one process: four per size
+    assert all(y["solve_group_size"] == 4 for y in b)           # one process: four per size (launch path: two halves on two streams)
     for x, y in zip(a, b):
+        assert x["kernel_mode"] == y["kernel_mode"] == 0
         assert x["metrics"]["iterations"] == y["metrics"]["iterations"] == 120
         for key in ("final_energy", "final_enstrophy", "final_palinstrophy", "u_momentum_residual", "psi_min"):
             assert x["metrics"][key] == y["metrics"][key], key

@@ -17,8 +17,8 @@ for leg in farm small_n cu_batch; do
 done
 find $out -name "*kernel_trace.csv" -delete
 for grp in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
-  tag=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $grp -d $out/pmc_$tag -o run --output-format csv -- python3 tools/pmc_run.py > $out/pmc_$tag.log 2>&1; echo "pmc $tag exit $?"
+  ctr=$(echo $grp | cut -d" " -f1)
+  rocprofv3 --kernel-trace --pmc $grp -d $out/pmc_$ctr -o run --output-format csv -- python3 tools/pmc_run.py > $out/pmc_$ctr.log 2>&1; echo "pmc $ctr exit $?"
 done
 python tools/pmc_summarize.py $out/pmc_TCC_HIT_sum $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_SQ_VALU_MFMA_BUSY_CYCLES > $out/pmc.json
 find $out -name "*counter_collection.csv" -delete; find $out -name "*kernel_trace.csv" -delete
