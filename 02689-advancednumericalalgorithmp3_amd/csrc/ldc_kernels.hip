@@ -1691,6 +1691,8 @@ struct ldc_solver {
   int ablate;
   double* stamps;            // ldc_debug_stamps
   hipGraphExec_t graph[2];   // [with_diagnostics]
+  hipGraphExec_t chunk_graph[2];   // a whole enqueue of chunk_iters[] iterations on one of the trial kernels (modes 3, 5) with its closing launches
+  int chunk_iters[2];
   hipStream_t capture_stream;
   int persist_mode;          // -1 auto, 0 launch per stage, 3 small-N kernel, 4 trial-per-CU kernel, 5 chip-wide kernel
   int n_cus;                 // compute units of the handle's device
@@ -2349,6 +2351,28 @@ int build_graph(ldc_solver* s, int with_diag) {
   return (int)ie;
 }
 
+int enqueue_wide_chunk(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
+  int e = launch_wide(s, n_iters, with_diag, st);
+  if (e) return e;
+  if ((e = launch_post(s, s->p.P, 0, 0, 0, st)) != 0) return e;
+  return with_diag ? launch_closing_diagnostics(s, st) : 0;
+}
+int build_chunk_graph(ldc_solver* s, int n_iters, int with_diag) {
+  std::lock_guard<std::mutex> lock(g_setup_mutex);
+  if (s->chunk_graph[with_diag]) { (void)hipGraphExecDestroy(s->chunk_graph[with_diag]); s->chunk_graph[with_diag] = nullptr; s->chunk_iters[with_diag] = 0; }
+  HIP_TRY(setup_stream(&s->capture_stream));
+  hipGraph_t g = nullptr;
+  HIP_TRY(hipStreamBeginCapture(s->capture_stream, kCaptureMode));
+  const int e = enqueue_wide_chunk(s, n_iters, with_diag, s->capture_stream);
+  const hipError_t ce = hipStreamEndCapture(s->capture_stream, &g);
+  if (e != 0) { if (g) (void)hipGraphDestroy(g); return e; }
+  if (ce != hipSuccess) return (int)ce;
+  const hipError_t ie = hipGraphInstantiate(&s->chunk_graph[with_diag], g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (ie == hipSuccess) s->chunk_iters[with_diag] = n_iters;
+  return (int)ie;
+}
+
 size_t batch_bytes(int B) {
   auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
   return 4 * up(sizeof(StageArgs) * B) + 6 * up(sizeof(PostArgs) * B) + up(sizeof(PalinArgs) * B) +
@@ -2499,6 +2523,8 @@ int ldc_solver_create(const ldc_problem* d, ldc_solver** out) {
   s->ablate = 0;
   s->stamps = nullptr;
   s->graph[0] = s->graph[1] = nullptr;
+  s->chunk_graph[0] = s->chunk_graph[1] = nullptr;
+  s->chunk_iters[0] = s->chunk_iters[1] = 0;
   s->capture_stream = nullptr;
   *out = s;
   return 0;
@@ -2509,6 +2535,7 @@ int ldc_solver_destroy(ldc_solver* s) {
   {
     std::lock_guard<std::mutex> lock(g_setup_mutex);
     for (int q = 0; q < 2; ++q) if (s->graph[q]) (void)hipGraphExecDestroy(s->graph[q]);
+    for (int q = 0; q < 2; ++q) if (s->chunk_graph[q]) (void)hipGraphExecDestroy(s->chunk_graph[q]);
   }
   delete s;
   return 0;
@@ -2524,6 +2551,10 @@ int ldc_solver_set_graph_iters(ldc_solver* s, int n) {
 int ldc_solver_set_persistent(ldc_solver* s, int mode) {
   if (!s) return LDC_E_STATE;
   if (mode < -1 || mode > 5 || mode == 1 || mode == 2) return LDC_E_ARG;          // (1, 2: the round-2 persistent kernel, removed)
+  {
+    std::lock_guard<std::mutex> lock(g_setup_mutex);          // (a chunk graph holds the kernel of the mode it was captured under)
+    for (int q = 0; q < 2; ++q) if (s->chunk_graph[q]) { (void)hipGraphExecDestroy(s->chunk_graph[q]); s->chunk_graph[q] = nullptr; s->chunk_iters[q] = 0; }
+  }
   s->persist_mode = mode;
   if (mode == 3 && !xcd_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }
   if (mode == 4 && !cu_available(s)) { s->persist_mode = -1; return LDC_E_ARG; }
@@ -2665,11 +2696,15 @@ int ldc_solver_enqueue(ldc_solver* s, int n_iters, int with_diag, void* stream) 
     return with_diag ? launch_closing_diagnostics(s, st) : 0;
   }
   if (n_iters > 1 && use_wide(s)) {
-    // the chip-wide trial kernel, then the transforms of the final pressure in the launch path's form
-    int e = launch_wide(s, n_iters, with_diag, st);
-    if (e) return e;
-    if ((e = launch_post(s, s->p.P, 0, 0, 0, st)) != 0) return e;
-    return with_diag ? launch_closing_diagnostics(s, st) : 0;
+    // the chip-wide trial kernel, then the transforms of the final pressure in the launch path's form and the closing record: five
+    // nodes (the flags' memset, the kernel, up to four closing launches) as ONE graph per chunk length -- launched one by one
+    // they cost 76 us of gaps per enqueue, as much as two iterations (the driver's bench line times chunks of 20)
+    if (s->chunk_graph[with_diag] == nullptr || s->chunk_iters[with_diag] != n_iters) {
+      const int e = build_chunk_graph(s, n_iters, with_diag);
+      if (e) return e;
+    }
+    HIP_TRY(hipGraphLaunch(s->chunk_graph[with_diag], st));
+    return 0;
   }
   if (n_iters > 1 && use_cu(s)) {
     int e = launch_cu(s, n_iters, with_diag, st);
