@@ -340,8 +340,9 @@ class SGSolver(LidDrivenCavitySolver):
             # to the launch path -- all the same way:
             # a configuration asks for "persistent where it applies", the levels of one FSG solve differ in size.  The
             # library knows the device (CUs, XCDs) and says LDC_E_ARG; nothing is asked of torch here: this runs in the
-            # worker threads of a sweep, where torch.cuda.get_device_properties raced inside torch's device bookkeeping
-            # ("Invalid device id" once, a process abort another time: round 3, test_gpu_config5_shape_batched_fsg_vs_oracle).
+            # worker threads of a sweep, where torch.cuda.get_device_properties once raised "Invalid device id" (round 3).
+            # (The silent process aborts of that round at test_gpu_config5_shape_batched_fsg_vs_oracle have no proven cause --
+            #  DESIGN.md 3 says what was changed and what is inferred; this is one of the two changes kept as hygiene.)
             rc = L.lib().ldc_solver_set_persistent(h, mode)
             if rc == -1 and mode in (3, 4, 5):
                 rc = L.lib().ldc_solver_set_persistent(h, 0)
