@@ -2067,14 +2067,19 @@ int launch_xcd(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
 }
 
 // ---- chip-wide trial kernel (mode 5) ---------------------------------------------------------------------------
-// Tail layout (index M-1 outside the tiles: T x T instead of (T+1) x (T+1) work-groups) whenever M = 16 T + 1 and the loop is
-// SG's (the smoother's stages carry their own pressure: its line nodes are not built); LDC_WIDE_LAYOUT=tiles keeps index M-1
-// inside the tiles where that fits (tests run both forms of one size).
+// Tail layout (index M-1 outside the tiles: T x T instead of (T+1) x (T+1) work-groups; M = 16 T + 1, SG's loop only -- the
+// smoother's stages carry their own pressure: its line nodes are not built) where the tiles do not fit the chip: N = 256.  Where both
+// fit (N = 96 ... 240) index M-1 inside the tiles is the faster form with diagnostics (N=128 24.3 against 26.4 us per iteration,
+// N=240 32.5 against 35.1; step-only they are equal: profiles/r04_wide_ab_layouts.log) -- the boundary-line jobs cost more than
+// 2 T + 1 more work-groups.  LDC_WIDE_LAYOUT=tail | tiles picks one where both are possible (tests run both forms of one size).
 bool wide_tail(const ldc_solver* s) {
   if ((s->p.M - 1) % 16 != 0 || s->p.stage_pressure != 0) return false;
+  const int Tt = (s->p.M + 15) / 16;
+  const bool tiles_fit = Tt <= kWT && Tt * Tt <= s->n_cus;
   const char* e = getenv("LDC_WIDE_LAYOUT");
-  if (e != nullptr && strcmp(e, "tiles") == 0 && (s->p.M + 15) / 16 <= kWT) return false;
-  return true;
+  if (e != nullptr && strcmp(e, "tiles") == 0 && tiles_fit) return false;
+  if (e != nullptr && strcmp(e, "tail") == 0) return true;
+  return !tiles_fit;
 }
 int wide_tiles(const ldc_solver* s) { return wide_tail(s) ? (s->p.M - 1) / 16 : (s->p.M + 15) / 16; }
 // one work-group per CU, all of them resident at once; the packed arrays hold T x T blocks; a partial-sum row per tile; the

@@ -22,7 +22,7 @@ log = logging.getLogger(__name__)
 # Measured on one MI355X.  Iterations to the reference's convergence criterion: BASELINE config 4 at full size
 # (profiles/r02_sweeps_streams.md).  Microseconds per full iteration (with E / Z / P) by the kernel a trial really gets:
 #   * a LONE trial: the one-XCD kernel up to N = 79 (profiles/r03_xcd_ab.log: N=16 10.8, 32 12.5, 64 16.9 -- the launch path it
-#     replaced took 28.6 / 29.6 / 30.6), the chip-wide kernel from N = 80 (profiles/r04_wide_ab_*.log: N=128 26.1, 256 35.1;
+#     replaced took 28.6 / 29.6 / 30.6), the chip-wide kernel from N = 80 (profiles/r04_wide_ab_*.log: N=128 24.3, 256 35.1;
 #     launch path 35.7 / 50.2);
 #   * a trial INSIDE a batch of equal-N trials (>= 8 of them; 1e6 / trial-iterations per second): N=16 and 32 on the
 #     trial-per-CU / one-XCD kernels (profiles/r03_cu_ab.log: 64 trials 5.7 M/s and 3.2 M/s), N=64 eight per launch on the
@@ -32,7 +32,7 @@ log = logging.getLogger(__name__)
 _SG_ITERATIONS = {(64, 100): 306441, (64, 400): 273012, (64, 1000): 247661,
                   (128, 100): 656077, (128, 400): 895532, (128, 1000): 832853,
                   (256, 100): 1050762, (256, 400): 1088448, (256, 1000): 1299041}
-_US_PER_ITERATION = {16: 10.8, 32: 12.5, 64: 16.9, 128: 26.1, 256: 35.1}               # SG, lone trial
+_US_PER_ITERATION = {16: 10.8, 32: 12.5, 64: 16.9, 128: 24.3, 256: 35.1}               # SG, lone trial
 _US_PER_ITERATION_BATCHED = {16: 0.175, 32: 0.31, 64: 2.14, 128: 7.6, 256: 42.7}       # SG, per trial of a batch
 _US_PER_SMOOTHER_ITERATION = {16: 10.5, 32: 11.7, 64: 16.1, 128: 29.1, 256: 71.4}      # FSG level, lone (N=256: launch path)
 _US_PER_SMOOTHER_ITERATION_BATCHED = {16: 0.32, 32: 0.81, 64: 2.14, 128: 12.2, 256: 68.0}

@@ -36,10 +36,9 @@ def test_wide_trajectory_vs_reference(golden_dir, monkeypatch, N, Re, K, layout)
     """The reference's own runs at N=128 and N=256, Re=1000 (g4c; BASELINE configs 3-5), diagnostics on.  N = 16 T runs in the
     tail layout (index M-1 outside the tiles: 64 / 256 work-groups, boundary-line jobs); N=128 also with index M-1 inside the
     tiles (81 work-groups) -- N=256 would need 289."""
-    if layout == "tiles":
-        if N == 256:
-            pytest.skip("17 x 17 tiles do not fit 256 CUs")
-        monkeypatch.setenv("LDC_WIDE_LAYOUT", "tiles")
+    if layout == "tiles" and N == 256:
+        pytest.skip("17 x 17 tiles do not fit 256 CUs")
+    monkeypatch.setenv("LDC_WIDE_LAYOUT", layout)
     g = np.load(golden_dir / f"g4c_traj_N{N}_Re{Re}_K{K}.npz")
     s = make(N, Re)
     assert mode_of(s) == 5
@@ -57,10 +56,9 @@ def test_wide_records_vs_oracle_all_tilings(monkeypatch, N, Re, layout):
     """Every history column against the oracle for T = 6 ... 16 tiles per axis (36 ... 256 work-groups), every remainder of T
     modulo the depth of the fragment ring.  N = 16 T runs in the tail layout (T x T work-groups, boundary-line jobs; N=96 ...
     256) and -- `tiles` -- with index M-1 inside (T+1) x (T+1) tiles like every other size."""
-    if layout == "tiles":
-        if N % 16 != 0 or N == 256:
-            pytest.skip("one layout for this size")
-        monkeypatch.setenv("LDC_WIDE_LAYOUT", "tiles")
+    if layout == "tiles" and (N % 16 != 0 or N == 256):
+        pytest.skip("one layout for this size")
+    monkeypatch.setenv("LDC_WIDE_LAYOUT", layout)          # (where both fit the library would take `tiles`)
     K = 24
     o = orc.OracleSG(N, Re)
     want = oracle_rows(o, K)
@@ -149,8 +147,7 @@ def test_wide_two_identical_runs_agree_bit_for_bit(monkeypatch, N, layout):
     bit for bit, 60 times over.  (Round 4: with the grad-omega contractions in the window of stage 2 the palinstrophy partials
     of some tiles differed between two such runs in 5 % of the iterations -- the trajectory tests against the reference saw it
     once in a few runs only.)"""
-    if layout == "tiles" and N % 16 == 0:
-        monkeypatch.setenv("LDC_WIDE_LAYOUT", "tiles")
+    monkeypatch.setenv("LDC_WIDE_LAYOUT", layout)
     A, B = make(N, 1000), make(N, 1000)
     assert mode_of(A) == 5 and mode_of(B) == 5
     for rep in range(60):

@@ -25,7 +25,9 @@ if kind == "smoother":
 diag = kind == "diag"
 s.run_iterations(256, diagnostics=diag)
 assert L.lib().ldc_solver_mode(s._handle) == 5
-T = (s.M - 1) // 16 if ((s.M - 1) % 16 == 0 and kind != "smoother" and os.environ.get("LDC_WIDE_LAYOUT") != "tiles") else (s.M + 15) // 16
+_tiles_fit = ((s.M + 15) // 16) ** 2 <= 256
+_lay = os.environ.get("LDC_WIDE_LAYOUT", "tiles" if _tiles_fit else "tail")
+T = (s.M - 1) // 16 if ((s.M - 1) % 16 == 0 and kind != "smoother" and (_lay == "tail" or not _tiles_fit)) else (s.M + 15) // 16
 nwg, W, P = T * T, 8, 12
 buf = torch.zeros(nwg * W * 4 * P, dtype=torch.float64, device="cuda")
 L.check(L.lib().ldc_debug_stamps(s._handle, buf.data_ptr()), "ldc_debug_stamps")
