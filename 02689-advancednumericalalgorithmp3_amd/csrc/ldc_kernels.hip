@@ -2359,8 +2359,8 @@ int build_graph(ldc_solver* s, int with_diag) {
 int enqueue_wide_chunk(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
   int e = launch_wide(s, n_iters, with_diag, st);
   if (e) return e;
-  if ((e = launch_post(s, s->p.P, 0, 0, 0, st)) != 0) return e;
-  return with_diag ? launch_closing_diagnostics(s, st) : 0;
+  // (the closing diagnostics' own post launch forms the transforms too: no second one in front of it)
+  return with_diag ? launch_closing_diagnostics(s, st) : launch_post(s, s->p.P, 0, 0, 0, st);
 }
 int build_chunk_graph(ldc_solver* s, int n_iters, int with_diag) {
   std::lock_guard<std::mutex> lock(g_setup_mutex);
@@ -2697,8 +2697,7 @@ int ldc_solver_enqueue(ldc_solver* s, int n_iters, int with_diag, void* stream) 
     // row-major T1T / T2T in the tail layout): whatever runs next finds the state it expects
     int e = launch_xcd(s, n_iters, with_diag, st);
     if (e) return e;
-    if ((e = launch_post(s, s->p.P, 0, 0, 0, st)) != 0) return e;
-    return with_diag ? launch_closing_diagnostics(s, st) : 0;
+    return with_diag ? launch_closing_diagnostics(s, st) : launch_post(s, s->p.P, 0, 0, 0, st);      // (either forms the transforms)
   }
   if (n_iters > 1 && use_wide(s)) {
     // the chip-wide trial kernel, then the transforms of the final pressure in the launch path's form and the closing record: five
@@ -2714,8 +2713,7 @@ int ldc_solver_enqueue(ldc_solver* s, int n_iters, int with_diag, void* stream) 
   if (n_iters > 1 && use_cu(s)) {
     int e = launch_cu(s, n_iters, with_diag, st);
     if (e) return e;
-    if ((e = launch_post(s, s->p.P, 0, 0, 0, st)) != 0) return e;
-    return with_diag ? launch_closing_diagnostics(s, st) : 0;
+    return with_diag ? launch_closing_diagnostics(s, st) : launch_post(s, s->p.P, 0, 0, 0, st);
   }
   int left = n_iters;
   if (left >= s->iters_per_graph) {
