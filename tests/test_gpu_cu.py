@@ -59,12 +59,13 @@ def test_cu_trajectory_vs_reference(golden_dir, N, Re, K):
 
 
 @pytest.mark.parametrize("N,Re", [(8, 100), (12, 400), (15, 100), (16, 400), (20, 100), (24, 400), (30, 1000), (31, 100),
-                                  (32, 400), (36, 100), (40, 100), (43, 400)])
+                                  (32, 400), (33, 100), (36, 100), (39, 400), (40, 100), (41, 100), (43, 400)])
 @pytest.mark.parametrize("diagnostics", [True, False])
 def test_cu_records_vs_oracle_all_sizes(N, Re, diagnostics):
     """Every history column against the oracle for 1, 4 and 9 waves, every residue of M mod 4 (the contraction range is
     ceil(M / 4) k-steps, zero padded) and both row strides of the LDS arrays, the reference's Optuna sizes 30 / 40 and their
-    FSG levels 15 / 20, up to the largest size the LDS holds (M = 44)."""
+    FSG levels 15 / 20, up to the largest size the LDS holds (M = 44); N = 33 ... 40 run in CORNER mode (eight tile waves, the
+    corner tile's products shared: (N - 31)^2 = 4 ... 81 corner nodes), N = 41 ... 43 on nine tile waves."""
     K = 40
     o = orc.OracleSG(N, Re)
     want = oracle_rows(o, K, diagnostics)
