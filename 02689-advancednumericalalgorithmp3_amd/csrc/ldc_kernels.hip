@@ -35,6 +35,7 @@
 #include <string.h>
 #include <mutex>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "ldc_hip.h"
@@ -1654,7 +1655,10 @@ __global__ __launch_bounds__(64) void mfma_selftest_kernel(const double* A, cons
   for (int r = 0; r < 4; ++r) D[((l >> 4) + 4 * r) * 16 + (l & 15)] = c[r];
 }
 
-__global__ __launch_bounds__(kThreads) void mfma_peak_kernel(double* sink, int iters) {
+// (launch bounds of 512: with fewer threads hipcc keeps the accumulators in AGPRs and copies all 64 registers to VGPRs and back
+//  around every trip of the loop -- 140 cycles per MFMA and wave instead of 64, which rounds 1 to 3 reported as the chip's
+//  sustained rate, 49 TFLOP/s; tools/probes/mfma_rate_probe.hip, profiles/r04_mfma_rate_probe.log)
+__global__ __launch_bounds__(512) void mfma_peak_kernel(double* sink, int iters) {
   const int l = threadIdx.x;
   double a = 1.0 + 1e-9 * l, b = 1.0 - 1e-9 * l;
   v4d c[8];
