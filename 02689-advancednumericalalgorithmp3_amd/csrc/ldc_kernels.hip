@@ -58,6 +58,9 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int kWaves = 4;          // waves per work-group == K-split factor
 constexpr int kThreads = 256;
+// launch bounds of the 256-thread kernels that issue MFMAs: told that a SIMD carries one wave, hipcc puts MFMA accumulators into
+// AGPRs and copies them to VGPRs and back around the loop (tools/probes/mfma_rate_probe.hip: 140 instead of 64 cycles per MFMA)
+constexpr int kMfmaBounds = 512;
 
 // ---------------------------------------------------------------------------------------
 // small device helpers
@@ -1240,7 +1243,7 @@ struct PostArgs {
 };
 
 template <bool BATCH>
-__global__ __launch_bounds__(kThreads) void post_kernel(const PostArgs a_val, const PostArgs* a_arr) {
+__global__ __launch_bounds__(kMfmaBounds) void post_kernel(const PostArgs a_val, const PostArgs* a_arr) {
   const PostArgs a = BATCH ? a_arr[blockIdx.y] : a_val;   // by value, see stage_kernel
   __shared__ __attribute__((aligned(16))) double red[kThreads * (PS_N + 2)];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1440,7 +1443,7 @@ struct PalinArgs {
 };
 
 template <bool BATCH>
-__global__ __launch_bounds__(kThreads) void palin_kernel(const PalinArgs a_val, const PalinArgs* a_arr) {
+__global__ __launch_bounds__(kMfmaBounds) void palin_kernel(const PalinArgs a_val, const PalinArgs* a_arr) {
   const PalinArgs& a = BATCH ? a_arr[blockIdx.y] : a_val;
   __shared__ __attribute__((aligned(16))) double red[kWaves * 2 * 4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1567,7 +1570,7 @@ struct GemmArgs {
   const double *lam_r, *lam_c;
 };
 
-__global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(kMfmaBounds) void gemm_nt_kernel(const GemmArgs a) {
   __shared__ __attribute__((aligned(16))) double red[kWaves * 1 * 4 * 64 + 16 * 17];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int I = blockIdx.y, J = blockIdx.x, r0 = 16 * I, c0 = 16 * J;
@@ -2163,11 +2166,11 @@ int launch_wide(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
 
 // ---- trial-per-CU kernel (mode 4) ------------------------------------------------------------------------------
 constexpr size_t kCuLdsMax = kLdsLimit - 128;        // (the kernel also has 48 bytes of static LDS: its control block)
-template <int T, bool EDGE, bool CORNER = false>
+template <int T, bool EDGE>
 int enable_cu_lds_t() {
-  const void* k[3] = {reinterpret_cast<const void*>(cu_kernel<T, EDGE, CORNER, false, false>),
-                      reinterpret_cast<const void*>(cu_kernel<T, EDGE, CORNER, false, true>),
-                      reinterpret_cast<const void*>(cu_kernel<T, EDGE, CORNER, true, false>)};
+  const void* k[3] = {reinterpret_cast<const void*>(cu_kernel<T, EDGE, false, false>),
+                      reinterpret_cast<const void*>(cu_kernel<T, EDGE, false, true>),
+                      reinterpret_cast<const void*>(cu_kernel<T, EDGE, true, false>)};
   for (const void* f : k) {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCuLdsMax);
     if (e != hipSuccess) return (int)e;
@@ -2177,20 +2180,13 @@ int enable_cu_lds_t() {
 int enable_cu_lds() {
   int e;
   if ((e = enable_cu_lds_t<1, false>()) != 0 || (e = enable_cu_lds_t<2, false>()) != 0 || (e = enable_cu_lds_t<3, false>()) != 0 ||
-      (e = enable_cu_lds_t<3, false, true>()) != 0 ||
       (e = enable_cu_lds_t<1, true>()) != 0 || (e = enable_cu_lds_t<2, true>()) != 0) return e;
   return 0;
-}
-// CORNER mode of the trial-per-CU kernel wherever it applies (M = 34 ... 41); LDC_CU_CORNER=0: nine tile waves there too (tests, A/B)
-bool cu_corner(int M) {
-  static const bool on = [] { const char* e = getenv("LDC_CU_CORNER"); return !(e != nullptr && e[0] == '0'); }();
-  return on && cu_corner_size(M);
 }
 // the stage state of the trial, in both orientations, and the operators fit one CU's LDS
 bool cu_available(const ldc_solver* s) {
   const int M = s->p.M;
-  return s->p.Mx == s->p.My && M >= 3 && M <= kCMaxM && cu_tiles(M) <= kCT && s->p.LD / 16 >= (M + 15) / 16 &&
-         cu_lds_bytes(M, cu_corner(M)) <= kCuLdsMax &&
+  return s->p.Mx == s->p.My && M >= 3 && M <= kCMaxM && cu_tiles(M) <= kCT && s->p.LD / 16 >= (M + 15) / 16 && cu_lds_bytes(M) <= kCuLdsMax &&
          s->p.partials_stride >= (int64_t)LDC_NPART;
 }
 bool use_cu(const ldc_solver* s) { return persistent_mode(s) == 4; }
@@ -2214,19 +2210,18 @@ CArgs make_cargs(const ldc_solver* s, int with_diag) {
   return a;
 }
 
-template <int T, bool EDGE, bool CORNER = false>
+template <int T, bool EDGE>
 int cu_launch_t(const CLaunch& cl, bool sp, bool diag, size_t lds_bytes, hipStream_t st) {
-  const dim3 grid(cl.B), block(64 * (CORNER ? 8 : T * T + ((EDGE || T < 3) ? 2 : 0)));
-  if (sp) hipLaunchKernelGGL((cu_kernel<T, EDGE, CORNER, true, false>), grid, block, lds_bytes, st, cl);
-  else if (diag) hipLaunchKernelGGL((cu_kernel<T, EDGE, CORNER, false, true>), grid, block, lds_bytes, st, cl);
-  else hipLaunchKernelGGL((cu_kernel<T, EDGE, CORNER, false, false>), grid, block, lds_bytes, st, cl);
+  const dim3 grid(cl.B), block(64 * (T * T + ((EDGE || T < 3) ? 2 : 0)));
+  if (sp) hipLaunchKernelGGL((cu_kernel<T, EDGE, true, false>), grid, block, lds_bytes, st, cl);
+  else if (diag) hipLaunchKernelGGL((cu_kernel<T, EDGE, false, true>), grid, block, lds_bytes, st, cl);
+  else hipLaunchKernelGGL((cu_kernel<T, EDGE, false, false>), grid, block, lds_bytes, st, cl);
   return (int)hipGetLastError();
 }
 int cu_launch_any(const CLaunch& cl, const ldc_solver* s0, int with_diag, hipStream_t st) {
   const int M = s0->p.M, T = cu_tiles(M);
   const bool sp = s0->p.stage_pressure != 0, diag = with_diag != 0;
-  const bool corner = cu_corner(M);
-  const size_t bytes = cu_lds_bytes(M, corner);
+  const size_t bytes = cu_lds_bytes(M);
   if (cu_edge(M)) {
     switch (T) {
       case 1: return cu_launch_t<1, true>(cl, sp, diag, bytes, st);
@@ -2237,7 +2232,7 @@ int cu_launch_any(const CLaunch& cl, const ldc_solver* s0, int with_diag, hipStr
   switch (T) {
     case 1: return cu_launch_t<1, false>(cl, sp, diag, bytes, st);
     case 2: return cu_launch_t<2, false>(cl, sp, diag, bytes, st);
-    case 3: return corner ? cu_launch_t<3, false, true>(cl, sp, diag, bytes, st) : cu_launch_t<3, false>(cl, sp, diag, bytes, st);
+    case 3: return cu_launch_t<3, false>(cl, sp, diag, bytes, st);
     default: return LDC_E_ARG;
   }
 }

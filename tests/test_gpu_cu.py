@@ -64,8 +64,7 @@ def test_cu_trajectory_vs_reference(golden_dir, N, Re, K):
 def test_cu_records_vs_oracle_all_sizes(N, Re, diagnostics):
     """Every history column against the oracle for 1, 4 and 9 waves, every residue of M mod 4 (the contraction range is
     ceil(M / 4) k-steps, zero padded) and both row strides of the LDS arrays, the reference's Optuna sizes 30 / 40 and their
-    FSG levels 15 / 20, up to the largest size the LDS holds (M = 44); N = 33 ... 40 run in CORNER mode (eight tile waves, the
-    corner tile's products shared: (N - 31)^2 = 4 ... 81 corner nodes), N = 41 ... 43 on nine tile waves."""
+    FSG levels 15 / 20, up to the largest size the LDS holds (M = 44)."""
     K = 40
     o = orc.OracleSG(N, Re)
     want = oracle_rows(o, K, diagnostics)
