@@ -23,10 +23,10 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE J
               `iterations_per_launch` = 2048 iterations on the launch stream (the three small launches that close a
               chunk's last record ride along: 0.03 % of it).  `launch_path` holds the same figures for the launch
               path's dominant kernel (the fused RK-stage kernel, 16 M^3 per launch, back-to-back launches), which
-              was the headline path until round 3.  `peak` = 78.6 TFLOP/s fp64 matrix (AMD datasheet).  `peak_measured` is the SUSTAINED fp64 MFMA rate of a
-              micro-benchmark in this run (~48 TFLOP/s: one v_mfma_f64_16x16x4 per ~100 cycles per
-              SIMD over 32 000 back-to-back MFMAs per wave) -- a power/clock figure, not the issue
-              limit: the 4-us K loop of the stage kernel runs at ~65 TFLOP/s.
+              was the headline path until round 3.  `peak` = 78.6 TFLOP/s fp64 matrix (AMD datasheet).  `peak_measured` is the fp64 MFMA rate of a
+              micro-benchmark in this run (32 000 back-to-back MFMAs per wave: ~77 TFLOP/s, one
+              v_mfma_f64_16x16x4 per 64 cycles and SIMD; the ~48 of rounds 1-3 was the benchmark's own
+              code -- AGPR round trips -- not the chip: DESIGN.md section 3).
 * cpu_baseline : the NumPy oracle (a port of the reference, pinned to its golden vectors)
               timed on this host's cores for a bounded sample of the same workload.
 * timed region: EXACTLY K iterations between barrier + synchronize on both sides, max over ranks -- repeated
