@@ -27,7 +27,7 @@ if kind == "smoother":
 diag = kind == "diag"
 b.run_iterations(256, diagnostics=diag)
 if any(int(L.lib().ldc_solver_mode(s._handle)) != 4 for s in b.solvers):
-    raise SystemExit(f"N={N}: the trial-per-CU kernel does not apply in this build (M = 41 ... 44 leave no room for the stamps)")
+    raise SystemExit(f"N={N}: the trial-per-CU kernel does not apply in this build (3 x 3 tiles, M = 34 ... 44: the LDS layout of that class leaves no room for the stamps)")
 W, P = 11, 8
 buf = torch.zeros(B * W * 4 * P, dtype=torch.float64, device="cuda")
 for q, s in enumerate(b.solvers):
