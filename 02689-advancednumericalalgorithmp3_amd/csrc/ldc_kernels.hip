@@ -2212,7 +2212,7 @@ CArgs make_cargs(const ldc_solver* s, int with_diag) {
 
 template <int T, bool EDGE>
 int cu_launch_t(const CLaunch& cl, bool sp, bool diag, size_t lds_bytes, hipStream_t st) {
-  const dim3 grid(cl.B), block(64 * (T * T + ((EDGE || T < 3) ? 2 : 0)));
+  const dim3 grid(cl.B), block(64 * (T * T + ((EDGE || T < 3) ? kCHelp : 0)));
   if (sp) hipLaunchKernelGGL((cu_kernel<T, EDGE, true, false>), grid, block, lds_bytes, st, cl);
   else if (diag) hipLaunchKernelGGL((cu_kernel<T, EDGE, false, true>), grid, block, lds_bytes, st, cl);
   else hipLaunchKernelGGL((cu_kernel<T, EDGE, false, false>), grid, block, lds_bytes, st, cl);

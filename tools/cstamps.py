@@ -39,8 +39,8 @@ st = buf.cpu().numpy().reshape(B, W, 4, P)[0]
 M = N + 1
 edge = M >= 17 and (M - 1) % 16 == 0
 T = (M - 1) // 16 if edge else (M + 15) // 16
-nw = T * T + (2 if (edge or T < 3) else 0)      # edge waves, or helper waves without nodes
-print(f"N={N} ({T}x{T} tile waves{' + 2 edge waves' if edge else (' + 2 helper waves' if T < 3 else '')}), {kind}, batch of {B}: cycles (s_memtime) relative to the stage entry of wave 0")
+nw = T * T + (4 if (edge or T < 3) else 0)      # four helper waves (EDGE mode: two of them are the edge waves)
+print(f"N={N} ({T}x{T} tile waves{' + 2 edge + 2 helper waves' if edge else (' + 4 helper waves' if T < 3 else '')}), {kind}, batch of {B}: cycles (s_memtime) relative to the stage entry of wave 0")
 names = {0: "entry", 6: "duty", 1: "products", 2: "barrier", 3: "epilogue", 4: "sums", 5: "barrier"}
 for k in range(4):
     base = st[0, k, 0]
