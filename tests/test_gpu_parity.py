@@ -45,6 +45,30 @@ def test_mfma_lane_maps():
     assert np.array_equal(dD.cpu().numpy(), A @ B)
 
 
+def test_mfma_peak_benchmark_issues_at_the_pipe_rate():
+    """`ldc_mfma_peak` (bench.py's `roofline.peak_measured`) must read the fp64 MFMA pipe, not its own code: built with launch
+    bounds of 256 threads it kept its accumulators in AGPRs, copied them around every trip and reported 49 TFLOP/s for three
+    rounds (one wave per SIMD: 140 cycles per MFMA instead of 64).  One wave per SIMD on every CU must come within 15 % of the
+    datasheet's 78.6 TFLOP/s (measured: 76.6, tools/probes/mfma_rate_probe.hip)."""
+    import torch
+    from solvers.spectral import ldc_lib as L
+    L.require_device()
+    lib, st = L.lib(), L.stream_ptr()
+    grid, iters = 256, 20000                       # 256 work-groups of four waves: one wave per SIMD
+    sink = torch.zeros(grid * 256 + 2, dtype=torch.float64, device="cuda")
+    L.check(lib.ldc_mfma_peak(sink.data_ptr(), 100, grid, st))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(lib.ldc_mfma_peak(sink.data_ptr(), iters, grid, st))
+    e1.record()
+    torch.cuda.synchronize()
+    tflops = grid * 4 * iters * 8 * 2048.0 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    cycles = float(sink[0].item()) / (iters * 8)
+    assert cycles < 70.0, f"{cycles:.1f} shader cycles per MFMA and wave (the pipe issues one per 64)"
+    assert tflops > 0.85 * 78.6, f"{tflops:.1f} TFLOP/s"
+
+
 @pytest.mark.parametrize("N", [16, 24])
 def test_single_residual_vs_reference(golden_dir, N):
     g = np.load(golden_dir / "g3_single_stage.npz")
