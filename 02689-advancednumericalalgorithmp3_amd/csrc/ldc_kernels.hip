@@ -1999,7 +1999,9 @@ int xcd_tiles(const ldc_solver* s) { return (s->p.M + 15) / 16; }
 // every tile's work-group on one XCD, one per CU; the packed arrays hold T x T blocks; a partial-sum row per tile
 bool xcd_available(const ldc_solver* s) {
   const int T = xcd_tiles(s);
-  return s->p.sync != nullptr && s->p.Mx == s->p.My && T <= kXT && T * T <= s->n_cus / s->n_xcds && s->p.LD / 16 >= T &&
+  // (nx != ny runs here too -- arrays and tiling of M = max(Mx, My), node classes and ring lines from (Mx, My) -- but not in a
+  //  batch: ldc_batch_create refuses unlike grids)
+  return s->p.sync != nullptr && T <= kXT && T * T <= s->n_cus / s->n_xcds && s->p.LD / 16 >= T &&
          s->p.partials_stride >= (int64_t)T * T * LDC_NPART;
 }
 bool use_xcd(const ldc_solver* s) { return persistent_mode(s) == 3; }
@@ -2009,6 +2011,7 @@ XArgs make_xargs(const ldc_solver* s, int with_diag, unsigned* sync) {
   XArgs a;
   memset(&a, 0, sizeof(a));
   a.M = p.M; a.LD = p.LD; a.NB = p.LD / 16; a.T = xcd_tiles(s);
+  a.Mx = p.Mx; a.My = p.My;
   a.with_diag = with_diag;
   a.nu = p.nu; a.beta2 = p.beta2;
   a.DxK = p.DxK; a.D2xK = p.D2xK; a.DyK = p.DyK; a.D2yK = p.D2yK;
@@ -2080,7 +2083,7 @@ int launch_xcd(ldc_solver* s, int n_iters, int with_diag, hipStream_t st) {
 // N=240 32.5 against 35.1; step-only they are equal: profiles/r04_wide_ab_layouts.log) -- the boundary-line jobs cost more than
 // 2 T + 1 more work-groups.  LDC_WIDE_LAYOUT=tail | tiles picks one where both are possible (tests run both forms of one size).
 bool wide_tail(const ldc_solver* s) {
-  if ((s->p.M - 1) % 16 != 0 || s->p.stage_pressure != 0) return false;
+  if ((s->p.M - 1) % 16 != 0 || s->p.stage_pressure != 0 || s->p.Mx != s->p.My) return false;
   const int Tt = (s->p.M + 15) / 16;
   const bool tiles_fit = Tt <= kWT && Tt * Tt <= s->n_cus;
   const char* e = getenv("LDC_WIDE_LAYOUT");
@@ -2093,7 +2096,8 @@ int wide_tiles(const ldc_solver* s) { return wide_tail(s) ? (s->p.M - 1) / 16 : 
 // flags and the ring scratch of the trial in its sync array
 bool wide_available(const ldc_solver* s) {
   const int T = wide_tiles(s);
-  return s->p.sync != nullptr && s->p.Mx == s->p.My && T >= kWTmin && T <= kWT && T * T <= s->n_cus && s->p.LD / 16 >= T &&
+  // (nx != ny: like the one-XCD kernel, in the layout with index M-1 inside the tiles)
+  return s->p.sync != nullptr && T >= kWTmin && T <= kWT && T * T <= s->n_cus && s->p.LD / 16 >= T &&
          s->p.partials_stride >= (int64_t)PS_N * ((T * T + 3) & ~3) && s->p.partials_stride % 4 == 0 && wlds_bytes(T) + 256 <= kLdsLimit;
 }
 bool use_wide(const ldc_solver* s) { return persistent_mode(s) == 5; }
@@ -2113,6 +2117,7 @@ WArgs make_wargs(const ldc_solver* s, int with_diag) {
   WArgs a;
   memset(&a, 0, sizeof(a));
   a.M = p.M; a.LD = p.LD; a.NB = p.LD / 16; a.T = wide_tiles(s);
+  a.Mx = p.Mx; a.My = p.My;
   a.tail = wide_tail(s) ? 1 : 0;
   a.with_diag = with_diag;
   a.nu = p.nu; a.beta2 = p.beta2;

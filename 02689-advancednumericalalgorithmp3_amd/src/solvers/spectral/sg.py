@@ -141,8 +141,9 @@ class SGSolver(LidDrivenCavitySolver):
         p = self.params
         # Independent x / y grids (reference sg.py:103-119).  nx != ny: the device arrays, the tiling and LD are built for
         # M = max(Mx, My); operators, vectors and fields of the shorter axis are zero padded like everything beyond M, the
-        # kernels take the node classes (wall, lid, interior) from (Mx, My), and the launch-per-stage path runs in the
-        # layout that keeps index M-1 inside the tiles (include/ldc_hip.h, ldc_problem::Mx).
+        # kernels take the node classes (wall, lid, interior) from (Mx, My), and every path that takes such grids (launch per
+        # stage, one-XCD kernel, chip-wide kernel) runs in the layout that keeps index M-1 inside the tiles
+        # (include/ldc_hip.h, ldc_problem::Mx).
         Mx, My = p.nx + 1, p.ny + 1
         M = max(Mx, My)
         self.M, self.Mx, self.My = M, Mx, My

@@ -17,7 +17,7 @@
  *    (dynamic-LDS attributes of its kernels are set there); using it with another device
  *    current returns LDC_E_STATE.
  *  - grids: M nodes per axis; independent x / y grids (reference sg.py:103-119: nx != ny; no shipped
- *    configuration uses it) through ldc_problem::Mx / My below (launch path only).  Lx != Ly is supported.
+ *    configuration uses it) through ldc_problem::Mx / My below (launch path, one-XCD and chip-wide kernel).  Lx != Ly is supported.
  *  - all 2-D arrays are row-major LD x LD doubles, zero padded, element [ix][iy]
  *    (reference sg.py:108, indexing="ij"); LD is a multiple of 16 and >= 16*T + 16.
  *  - "transposed copy" XT means XT[iy][ix] = X[ix][iy]; the kernels keep both so that
@@ -155,8 +155,9 @@ typedef struct ldc_problem {
                          the launch-per-stage path is then the only one                  */
   /* independent x / y grids (reference sg.py:103-119: nx != ny).  0 = M.  M is then the LARGER of the two node  */
   /* counts -- the tiling, LD and every padded array are built for it, tail = 0 --, the operators and vectors of  */
-  /* the shorter axis are zero padded like everything else, and only the launch-per-stage path runs (modes 3 / 4  */
-  /* answer LDC_E_ARG).                                                                                           */
+  /* the shorter axis are zero padded like everything else; the launch-per-stage path, the one-XCD kernel (mode 3) */
+  /* and the chip-wide kernel (mode 5, index M-1 inside the tiles) run such grids; the trial-per-CU kernel (mode  */
+  /* 4) answers LDC_E_ARG.                                                                                        */
   int32_t Mx, My;     /* nodes along x (first index) / y (second index)                                           */
 } ldc_problem;
 

@@ -1,7 +1,7 @@
 """nx != ny: the reference builds the x and y grids independently (sg.py:103-119).  On the device the arrays, the tiling
 and LD are built for M = max(nx, ny) + 1, the shorter axis is zero padding, the kernels take wall / lid / interior from
-(Mx, My), and the launch-per-stage path runs (include/ldc_hip.h, ldc_problem::Mx).  Pinned against the reference's own
-runs (tests/golden/g13_unequal_grids.*, made by tests/golden/make_golden.py G13) and against the oracle."""
+(Mx, My); the launch-per-stage path, the one-XCD kernel (M <= 80) and the chip-wide kernel (above) run them (include/ldc_hip.h, ldc_problem::Mx).  Pinned
+against the reference's own runs (tests/golden/g13_unequal_grids.*, made by tests/golden/make_golden.py G13) and against the oracle."""
 import json
 
 import numpy as np
@@ -41,16 +41,18 @@ def test_oracle_matches_the_reference_on_unequal_grids(golden_dir, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 3])
 @pytest.mark.parametrize("name", ["nx24_ny40", "nx40_ny20", "nx17_ny32"])
-def test_gpu_trajectory_vs_reference_on_unequal_grids(golden_dir, name):
+def test_gpu_trajectory_vs_reference_on_unequal_grids(golden_dir, name, mode):
     """K steps from rest with every record column, omega, psi and the vortex metrics of the end state: x longer than y, y
-    longer than x, Lx != Ly, the Saad lid; one of the sizes has 16 T + 1 nodes on one axis only (no tail layout)."""
+    longer than x, Lx != Ly, the Saad lid; one of the sizes has 16 T + 1 nodes on one axis only (no tail layout).  On the
+    launch-per-stage path and on the one-XCD kernel (the library's own choice for a lone trial of these sizes)."""
     from solvers.spectral import ldc_lib as L
     g, meta = _load(golden_dir)
     c = meta[name]
-    s = make(c["nx"], c["ny"], c["Re"], **c["kw"])
+    s = make(c["nx"], c["ny"], c["Re"], persistent=mode, **c["kw"])
     rec = s.run_iterations(c["K"])
-    assert L.lib().ldc_solver_mode(s._handle) == 0                    # the launch-per-stage path
+    assert L.lib().ldc_solver_mode(s._handle) == mode
     assert rec.shape == (c["K"], 8)
     assert np.max(np.abs(s.arrays.u - g[f"{name}_u"])) < 1e-12
     assert np.max(np.abs(s.arrays.v - g[f"{name}_v"])) < 1e-12
@@ -72,9 +74,12 @@ def test_gpu_trajectory_vs_reference_on_unequal_grids(golden_dir, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("auto", [True, False])
 @pytest.mark.parametrize("nx,ny,Re", [(64, 32, 400.0), (30, 100, 100.0), (48, 129, 100.0)])
-def test_gpu_records_vs_oracle_on_unequal_grids(nx, ny, Re):
-    """Larger and more lopsided grids against the oracle (several tiles per axis, one axis with 16 T + 2 nodes)."""
+def test_gpu_records_vs_oracle_on_unequal_grids(nx, ny, Re, auto):
+    """Larger and more lopsided grids against the oracle (several tiles per axis, one axis with 16 T + 2 nodes), on the
+    library's own choice -- the one-XCD kernel up to M = 80, the chip-wide kernel above (index M-1 inside the tiles) -- and on
+    the launch-per-stage path."""
     K = 40
     o = orc.OracleSG(nx, Re, ny=ny)
     up, rows = None, []
@@ -84,8 +89,10 @@ def test_gpu_records_vs_oracle_on_unequal_grids(nx, ny, Re):
         nrm = lambda a, b: np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-12)      # noqa: E731
         rows.append([max(nrm(o.u, up), nrm(o.v, vp)), *o.residual_norms(), o.energy(), o.enstrophy(), o.palinstrophy(), dt])
     want = np.array(rows)
-    s = make(nx, ny, Re)
+    s = make(nx, ny, Re) if auto else make(nx, ny, Re, persistent=0)
     rec = s.run_iterations(K)
+    from solvers.spectral import ldc_lib as L
+    assert L.lib().ldc_solver_mode(s._handle) == ((3 if max(nx, ny) <= 79 else 5) if auto else 0)     # (64 x 32: 5 x 5 tiles on one XCD)
     Mx, My = nx + 1, ny + 1
     assert np.max(np.abs(s.arrays.u.reshape(Mx, My) - o.u)) < 1e-12
     assert np.max(np.abs(s.arrays.v.reshape(Mx, My) - o.v)) < 1e-12
