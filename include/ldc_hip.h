@@ -234,7 +234,7 @@ int ldc_solver_set_graph_iters(ldc_solver *s, int iters_per_graph);
 /*  thresholds are where the two lines cross: profiles/r03_cu_ab_thresholds.log)                                                                                     */
 #define LDC_CU_AUTO_TRIALS 80        /* ceil(M/16) <= 2                                                  */
 #define LDC_CU_AUTO_TRIALS_T3 80     /* ceil(M/16) == 3                                                  */
-#define LDC_CU_AUTO_TRIALS_M33 32    /* M == 33 (N = 32): four tile waves + two edge waves instead of nine tile waves */
+#define LDC_CU_AUTO_TRIALS_M33 32    /* M == 33 (N = 32): four tile waves + two edge + two helper waves, not nine tile waves */
 int ldc_solver_set_persistent(ldc_solver *s, int mode);
 /* the mode ldc_solver_enqueue will really use for more than one iteration (0, 1, 2, 3 or 4): what set_persistent asked   */
 /* for, resolved against what the handle's size and device allow.  A host that drives several streams uses it to keep  */
