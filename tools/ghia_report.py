@@ -89,7 +89,7 @@ for case in a.cases.split(","):
         s.solve()
     stop.set()
     m = s.metrics
-    rec = dict(N=N, Re=Re, tolerance=a.tolerance, iterations=m.iterations, converged=m.converged, wall_time_seconds=m.wall_time_seconds,
+    rec = dict(N=N, Re=Re, tolerance=a.tolerance, kernel_mode=getattr(s, 'kernel_mode', None), iterations=m.iterations, converged=m.converged, wall_time_seconds=m.wall_time_seconds,
                steps_per_second=m.iterations / m.wall_time_seconds, total_seconds=time.perf_counter() - t0,
                final_residual=m.final_residual, psi_min=m.psi_min, psi_min_x=m.psi_min_x, psi_min_y=m.psi_min_y,
                omega_center=m.omega_center, psi_BR=m.psi_BR, psi_BL=m.psi_BL, E=m.final_energy, Z=m.final_enstrophy,
